@@ -1,0 +1,445 @@
+// igt_api.hip -- the C ABI declared in include/igtmpc.h (handle management, argument
+// validation, host staging, launches).  No exceptions cross the boundary.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "igt_launch.h"
+#include "igtmpc.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(IGT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+}  // namespace
+
+struct igt_handle {
+    igt_params p;
+    igt::KP kp;
+    int device;
+    hipStream_t stream;
+    double* d_cinf;
+    double* d_table;
+    bool table_set;
+    bool net_set;
+    void* d_stage;
+    size_t stage_bytes;
+    bool prof;
+    hipEvent_t ev[3];
+    bool ev_recorded;
+    int nc;
+};
+
+namespace {
+
+int isqrt_exact(int c) {
+    int g = (int)std::lround(std::sqrt((double)c));
+    return g * g == c ? g : -1;
+}
+
+int validate(const igt_params& p, std::string& why) {
+    if (p.N < 1 || p.N > IGT_MAX_N) { why = "N must be in [1, IGT_MAX_N]"; return -1; }
+    if (p.n_rk4 < 1 || p.n_rk4 > 64) { why = "n_rk4 must be in [1, 64]"; return -1; }
+    if (p.C < 64 || p.C % 64) { why = "C must be a positive multiple of 64"; return -1; }
+    if (p.n_obs < 0 || p.n_obs > IGT_MAX_OBS) { why = "n_obs must be in [0, IGT_MAX_OBS]"; return -1; }
+    if (!(p.dt > 0) || !(p.l_r > 0) || !(p.l_f > 0)) { why = "dt, l_r, l_f must be positive"; return -1; }
+    if (p.cand_mode == IGT_CAND_LATTICE) {
+        const int g = isqrt_exact(p.C);
+        if (g < 2 || 64 % g) { why = "lattice candidates need C = G*G with G in {2,4,8,16,32,64}; use IGT_CAND_TABLE"; return -1; }
+    } else if (p.cand_mode != IGT_CAND_TABLE) {
+        why = "unknown cand_mode"; return -1;
+    }
+    if (p.cost_mode != IGT_COST_PROGRESS && p.cost_mode != IGT_COST_VALUE_NET) { why = "unknown cost_mode"; return -1; }
+    if (!(p.v_min <= p.v_max) || !(p.a_min <= p.a_max) || !(p.df_max >= 0)) { why = "inconsistent limits"; return -1; }
+    if (!(p.feas_tol >= 0)) { why = "feas_tol must be >= 0"; return -1; }
+    return 0;
+}
+
+igt::KP make_kp(const igt_params& p, int F) {
+    igt::KP k;
+    k.N = p.N; k.n_rk4 = p.n_rk4; k.C = p.C; k.n_obs = p.n_obs;
+    k.cand_mode = p.cand_mode; k.cost_mode = p.cost_mode; k.F = F;
+    k.G = p.cand_mode == IGT_CAND_LATTICE ? isqrt_exact(p.C) : 1;
+    k.dt = p.dt;
+    k.h = p.dt / p.n_rk4;                      // frenet.py:93
+    k.l_r = p.l_r;
+    k.lr_ratio = p.l_r / (p.l_f + p.l_r);      // frenet.py:72
+    k.v_min = p.v_min; k.v_max = p.v_max; k.a_min = p.a_min; k.a_max = p.a_max; k.df_max = p.df_max;
+    k.rate_a = p.dt * p.jerk_limit;            // mpc.py:304
+    k.rate_df = p.dt * p.steer_rate_limit;     // mpc.py:306
+    k.ey_lim = p.ey_lim;
+    k.dmin2 = p.d_min * p.d_min;               // mpc.py:226
+    k.w_u = p.w_u;
+    k.tol = p.feas_tol;
+    return k;
+}
+
+int ensure_stage(igt_handle* h, size_t bytes) {
+    if (bytes <= h->stage_bytes) return 0;
+    if (h->d_stage) { HIPCHK(hipFree(h->d_stage)); h->d_stage = nullptr; h->stage_bytes = 0; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    HIPCHK(hipMalloc(&h->d_stage, want));
+    h->stage_bytes = want;
+    return 0;
+}
+
+struct Arena {   // carves 256-byte aligned pieces out of the staging buffer
+    char* base;
+    size_t off;
+    template <typename U> U* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        U* p = reinterpret_cast<U*>(base + off);
+        off += n * sizeof(U);
+        return p;
+    }
+};
+
+template <typename T>
+int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* kparams, const uint32_t* flags,
+               const T* obs_xy, const T* tv_sv, const T* enc, T* x_out, T* u_out, T* cost_out, int32_t* argmin_out,
+               int32_t* status_out, int mem, void* stream) {
+    if (!h) return fail(IGT_E_INVALID, "null handle");
+    if (B < 0) return fail(IGT_E_INVALID, "B < 0");
+    if (B == 0) return IGT_OK;
+    if (!x0 || !u_prev || !kparams || !flags || !x_out || !u_out || !cost_out || !argmin_out || !status_out)
+        return fail(IGT_E_INVALID, "null buffer");
+    const igt_params& p = h->p;
+    if (p.n_obs > 0 && !obs_xy) return fail(IGT_E_INVALID, "obs_xy is null but n_obs > 0");
+    if (p.cand_mode == IGT_CAND_TABLE && !h->table_set) return fail(IGT_E_STATE, "candidate table not set");
+    if (p.cost_mode == IGT_COST_VALUE_NET) {
+        if (!h->net_set) return fail(IGT_E_STATE, "value net not set");
+        if (!tv_sv || !enc) return fail(IGT_E_INVALID, "tv_sv / enc required for the value-net cost");
+        return fail(IGT_E_INVALID, "value-net cost is not available in this build");
+    }
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const size_t n_x = (size_t)B * 7, n_u = (size_t)B * 2, n_k = (size_t)B * 3;
+    const size_t n_obs = (size_t)B * p.n_obs * 2 * (p.N + 1);
+    const size_t n_xo = (size_t)B * 7 * (p.N + 1), n_uo = (size_t)B * 2 * p.N;
+
+    igt::SolveArgs<T> A{};
+    A.table = h->table_set ? h->d_table : nullptr;
+    A.cinf = h->kp.F > 0 ? h->d_cinf : nullptr;
+    if (mem == IGT_MEM_DEVICE) {
+        A.x0 = x0; A.u_prev = u_prev; A.kparams = kparams; A.flags = flags; A.obs = obs_xy;
+        A.tv_sv = tv_sv; A.enc = enc;
+        A.x_out = x_out; A.u_out = u_out; A.cost_out = cost_out; A.argmin_out = argmin_out; A.status_out = status_out;
+    } else if (mem == IGT_MEM_HOST) {
+        const size_t bytes = (n_x + n_u + n_k + n_obs + n_xo + n_uo + B) * sizeof(T) + (size_t)B * 12 + 16 * 256;
+        if (int rc = ensure_stage(h, bytes)) return rc;
+        Arena ar{(char*)h->d_stage, 0};
+        T* dx0 = ar.take<T>(n_x); T* dup = ar.take<T>(n_u); T* dk = ar.take<T>(n_k);
+        uint32_t* dfl = ar.take<uint32_t>(B); T* dob = ar.take<T>(n_obs ? n_obs : 1);
+        T* dxo = ar.take<T>(n_xo); T* duo = ar.take<T>(n_uo); T* dco = ar.take<T>(B);
+        int32_t* dam = ar.take<int32_t>(B); int32_t* dst = ar.take<int32_t>(B);
+        HIPCHK(hipMemcpyAsync(dx0, x0, n_x * sizeof(T), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(dup, u_prev, n_u * sizeof(T), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(dk, kparams, n_k * sizeof(T), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(dfl, flags, (size_t)B * 4, hipMemcpyHostToDevice, st));
+        if (n_obs) HIPCHK(hipMemcpyAsync(dob, obs_xy, n_obs * sizeof(T), hipMemcpyHostToDevice, st));
+        A.x0 = dx0; A.u_prev = dup; A.kparams = dk; A.flags = dfl; A.obs = dob;
+        A.x_out = dxo; A.u_out = duo; A.cost_out = dco; A.argmin_out = dam; A.status_out = dst;
+    } else {
+        return fail(IGT_E_INVALID, "mem must be IGT_MEM_DEVICE or IGT_MEM_HOST");
+    }
+
+    if (h->prof) HIPCHK(hipEventRecord(h->ev[0], st));
+    HIPCHK(igt::launch_search<T>(h->kp, B, A, h->nc, st));
+    if (h->prof) HIPCHK(hipEventRecord(h->ev[1], st));
+    HIPCHK(igt::launch_emit<T>(h->kp, B, A, st));
+    if (h->prof) { HIPCHK(hipEventRecord(h->ev[2], st)); h->ev_recorded = true; }
+
+    if (mem == IGT_MEM_HOST) {
+        HIPCHK(hipMemcpyAsync(x_out, A.x_out, n_xo * sizeof(T), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(u_out, A.u_out, n_uo * sizeof(T), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(cost_out, A.cost_out, (size_t)B * sizeof(T), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(argmin_out, A.argmin_out, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(status_out, A.status_out, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return IGT_OK;
+}
+
+template <typename T>
+int rollout_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* kparams, const uint32_t* flags,
+                 const T* obs_xy, T* X_all, T* U_all, T* cost_all, uint32_t* viol_all, int mem, void* stream) {
+    if (!h) return fail(IGT_E_INVALID, "null handle");
+    if (B < 0) return fail(IGT_E_INVALID, "B < 0");
+    if (B == 0) return IGT_OK;
+    if (!x0 || !u_prev || !kparams || !flags || !cost_all || !viol_all) return fail(IGT_E_INVALID, "null buffer");
+    const igt_params& p = h->p;
+    if (p.n_obs > 0 && !obs_xy) return fail(IGT_E_INVALID, "obs_xy is null but n_obs > 0");
+    if (p.cand_mode == IGT_CAND_TABLE && !h->table_set) return fail(IGT_E_STATE, "candidate table not set");
+    if (p.cost_mode != IGT_COST_PROGRESS) return fail(IGT_E_INVALID, "value-net cost is not available in this build");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const size_t n_x = (size_t)B * 7, n_u = (size_t)B * 2, n_k = (size_t)B * 3;
+    const size_t n_obs = (size_t)B * p.n_obs * 2 * (p.N + 1);
+    const size_t n_X = (size_t)B * p.C * 7 * (p.N + 1), n_U = (size_t)B * p.C * 2 * p.N, n_c = (size_t)B * p.C;
+    igt::SolveArgs<T> A{};
+    A.table = h->table_set ? h->d_table : nullptr;
+    A.cinf = h->kp.F > 0 ? h->d_cinf : nullptr;
+    T *dX = X_all, *dU = U_all, *dc = cost_all;
+    uint32_t* dv = viol_all;
+    if (mem == IGT_MEM_DEVICE) {
+        A.x0 = x0; A.u_prev = u_prev; A.kparams = kparams; A.flags = flags; A.obs = obs_xy;
+    } else if (mem == IGT_MEM_HOST) {
+        const size_t bytes = (n_x + n_u + n_k + n_obs + (X_all ? n_X : 0) + (U_all ? n_U : 0) + n_c) * sizeof(T) +
+                             n_c * 4 + (size_t)B * 4 + 16 * 256;
+        if (int rc = ensure_stage(h, bytes)) return rc;
+        Arena ar{(char*)h->d_stage, 0};
+        T* dx0 = ar.take<T>(n_x); T* dup = ar.take<T>(n_u); T* dk = ar.take<T>(n_k);
+        uint32_t* dfl = ar.take<uint32_t>(B); T* dob = ar.take<T>(n_obs ? n_obs : 1);
+        dX = X_all ? ar.take<T>(n_X) : nullptr;
+        dU = U_all ? ar.take<T>(n_U) : nullptr;
+        dc = ar.take<T>(n_c); dv = ar.take<uint32_t>(n_c);
+        HIPCHK(hipMemcpyAsync(dx0, x0, n_x * sizeof(T), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(dup, u_prev, n_u * sizeof(T), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(dk, kparams, n_k * sizeof(T), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(dfl, flags, (size_t)B * 4, hipMemcpyHostToDevice, st));
+        if (n_obs) HIPCHK(hipMemcpyAsync(dob, obs_xy, n_obs * sizeof(T), hipMemcpyHostToDevice, st));
+        A.x0 = dx0; A.u_prev = dup; A.kparams = dk; A.flags = dfl; A.obs = dob;
+    } else {
+        return fail(IGT_E_INVALID, "mem must be IGT_MEM_DEVICE or IGT_MEM_HOST");
+    }
+    HIPCHK(igt::launch_rollout_all<T>(h->kp, B, A, dX, dU, dc, dv, st));
+    if (mem == IGT_MEM_HOST) {
+        if (X_all) HIPCHK(hipMemcpyAsync(X_all, dX, n_X * sizeof(T), hipMemcpyDeviceToHost, st));
+        if (U_all) HIPCHK(hipMemcpyAsync(U_all, dU, n_U * sizeof(T), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(cost_all, dc, n_c * sizeof(T), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(viol_all, dv, n_c * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return IGT_OK;
+}
+
+template <typename T>
+int cartesian_impl(igt_handle* h, int32_t n, int32_t steps, const T* z0, const T* u, T* z_out, int mem, void* stream) {
+    if (!h) return fail(IGT_E_INVALID, "null handle");
+    if (n < 0 || steps < 0) return fail(IGT_E_INVALID, "negative size");
+    if (n == 0) return IGT_OK;
+    if (!z0 || !z_out || (steps > 0 && !u)) return fail(IGT_E_INVALID, "null buffer");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const size_t n_z = (size_t)n * 4, n_u = (size_t)n * 2 * steps, n_o = (size_t)n * 4 * (steps + 1);
+    const T *dz = z0, *du = u;
+    T* dout = z_out;
+    if (mem == IGT_MEM_HOST) {
+        if (int rc = ensure_stage(h, (n_z + n_u + n_o) * sizeof(T) + 8 * 256)) return rc;
+        Arena ar{(char*)h->d_stage, 0};
+        T* a = ar.take<T>(n_z); T* b = ar.take<T>(n_u ? n_u : 1); dout = ar.take<T>(n_o);
+        HIPCHK(hipMemcpyAsync(a, z0, n_z * sizeof(T), hipMemcpyHostToDevice, st));
+        if (n_u) HIPCHK(hipMemcpyAsync(b, u, n_u * sizeof(T), hipMemcpyHostToDevice, st));
+        dz = a; du = b;
+    } else if (mem != IGT_MEM_DEVICE) {
+        return fail(IGT_E_INVALID, "mem must be IGT_MEM_DEVICE or IGT_MEM_HOST");
+    }
+    HIPCHK(igt::launch_cartesian<T>(n, steps, h->p.dt, h->p.l_r, h->p.l_f, dz, du, dout, st));
+    if (mem == IGT_MEM_HOST) {
+        HIPCHK(hipMemcpyAsync(z_out, dout, n_o * sizeof(T), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return IGT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int igt_version(void) { return IGT_VERSION; }
+
+const char* igt_last_error(void) { return g_err.c_str(); }
+
+int igt_params_default(igt_params* p) {
+    if (!p) return fail(IGT_E_INVALID, "null params");
+    std::memset(p, 0, sizeof(*p));
+    p->N = 20; p->n_rk4 = 4; p->C = 256; p->n_obs = 1;
+    p->cand_mode = IGT_CAND_LATTICE; p->cost_mode = IGT_COST_PROGRESS;
+    p->dt = 0.1;
+    p->l_r = 4.47 / 2; p->l_f = 4.47 / 2;                 /* mpc.py:48-50 */
+    p->v_min = 0; p->v_max = 5; p->a_min = -4; p->a_max = 3; p->df_max = 1;  /* mpc.py:57-62 */
+    p->jerk_limit = 0.9; p->steer_rate_limit = 0.7;       /* mpc.py:55-56 */
+    p->ey_lim = 0.2;                                      /* mpc.py:61 */
+    p->d_min = 2 * 2.8;                                   /* mpc.py:45, fourwayint.yaml:9 */
+    p->w_u = 0.05;                                        /* mpc.py:362 */
+    p->feas_tol = 1e-6;
+    return IGT_OK;
+}
+
+int igt_create(const igt_params* p, int device, igt_handle** out) {
+    if (!p || !out) return fail(IGT_E_INVALID, "null argument");
+    std::string why;
+    if (validate(*p, why)) return fail(IGT_E_INVALID, why);
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(IGT_E_INVALID, "no such device");
+    HIPCHK(hipSetDevice(device));
+    igt_handle* h = new (std::nothrow) igt_handle();
+    if (!h) return fail(IGT_E_NOMEM, "out of host memory");
+    h->p = *p;
+    h->kp = make_kp(*p, 0);
+    h->device = device;
+    h->d_cinf = nullptr; h->d_table = nullptr; h->table_set = false; h->net_set = false;
+    h->d_stage = nullptr; h->stage_bytes = 0;
+    h->prof = false; h->ev_recorded = false;
+    h->nc = 2;
+    if (const char* e = std::getenv("IGT_NC")) {
+        const int v = std::atoi(e);
+        if (v == 1 || v == 2 || v == 4) h->nc = v;
+    }
+    while ((p->C / 64) % h->nc) h->nc /= 2;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail(IGT_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    for (int i = 0; i < 3; ++i) {
+        e = hipEventCreate(&h->ev[i]);
+        if (e != hipSuccess) { delete h; return fail(IGT_E_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
+    }
+    *out = h;
+    return IGT_OK;
+}
+
+int igt_destroy(igt_handle* h) {
+    if (!h) return IGT_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->d_cinf) (void)hipFree(h->d_cinf);
+    if (h->d_table) (void)hipFree(h->d_table);
+    if (h->d_stage) (void)hipFree(h->d_stage);
+    for (int i = 0; i < 3; ++i) (void)hipEventDestroy(h->ev[i]);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return IGT_OK;
+}
+
+int igt_get_params(const igt_handle* h, igt_params* out) {
+    if (!h || !out) return fail(IGT_E_INVALID, "null argument");
+    *out = h->p;
+    return IGT_OK;
+}
+
+int igt_set_cinf(igt_handle* h, const double* A, const double* b, int32_t F) {
+    if (!h) return fail(IGT_E_INVALID, "null handle");
+    if (F < 0 || F > IGT_MAX_CINF) return fail(IGT_E_INVALID, "F must be in [0, IGT_MAX_CINF]");
+    if (F > 0 && (!A || !b)) return fail(IGT_E_INVALID, "null table");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->d_cinf) { HIPCHK(hipFree(h->d_cinf)); h->d_cinf = nullptr; }
+    if (F > 0) {
+        std::vector<double> packed((size_t)F * 3);
+        for (int m = 0; m < F; ++m) {
+            packed[m * 3 + 0] = A[m * 2 + 0];
+            packed[m * 3 + 1] = A[m * 2 + 1];
+            packed[m * 3 + 2] = b[m];
+        }
+        HIPCHK(hipMalloc((void**)&h->d_cinf, packed.size() * sizeof(double)));
+        HIPCHK(hipMemcpy(h->d_cinf, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    h->kp.F = F;
+    return IGT_OK;
+}
+
+int igt_set_candidate_table(igt_handle* h, const double* U) {
+    if (!h || !U) return fail(IGT_E_INVALID, "null argument");
+    if (h->p.cand_mode != IGT_CAND_TABLE) return fail(IGT_E_STATE, "handle was not created with IGT_CAND_TABLE");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t n = (size_t)h->p.C * 2 * h->p.N;
+    if (!h->d_table) HIPCHK(hipMalloc((void**)&h->d_table, n * sizeof(double)));
+    HIPCHK(hipMemcpy(h->d_table, U, n * sizeof(double), hipMemcpyHostToDevice));
+    h->table_set = true;
+    return IGT_OK;
+}
+
+int igt_set_value_net(igt_handle* h, int32_t n_layers, const int32_t* dims, const double* weights, const double* Wn,
+                      const double* mu_f, double sigma_t, double mu_t) {
+    (void)n_layers; (void)dims; (void)weights; (void)Wn; (void)mu_f; (void)sigma_t; (void)mu_t;
+    if (!h) return fail(IGT_E_INVALID, "null handle");
+    return fail(IGT_E_INVALID, "value-net cost is not available in this build");
+}
+
+int igt_solve_batch_f32(igt_handle* h, int32_t B, const float* x0, const float* u_prev, const float* kparams,
+                        const uint32_t* flags, const float* obs_xy, const float* tv_sv, const float* enc, float* x_out,
+                        float* u_out, float* cost_out, int32_t* argmin_out, int32_t* status_out, int mem, void* stream) {
+    return solve_impl<float>(h, B, x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, x_out, u_out, cost_out, argmin_out,
+                             status_out, mem, stream);
+}
+int igt_solve_batch_f64(igt_handle* h, int32_t B, const double* x0, const double* u_prev, const double* kparams,
+                        const uint32_t* flags, const double* obs_xy, const double* tv_sv, const double* enc,
+                        double* x_out, double* u_out, double* cost_out, int32_t* argmin_out, int32_t* status_out,
+                        int mem, void* stream) {
+    return solve_impl<double>(h, B, x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, x_out, u_out, cost_out,
+                              argmin_out, status_out, mem, stream);
+}
+
+int igt_rollout_batch_f32(igt_handle* h, int32_t B, const float* x0, const float* u_prev, const float* kparams,
+                          const uint32_t* flags, const float* obs_xy, const float* tv_sv, const float* enc,
+                          float* X_all, float* U_all, float* cost_all, uint32_t* viol_all, int mem, void* stream) {
+    (void)tv_sv; (void)enc;
+    return rollout_impl<float>(h, B, x0, u_prev, kparams, flags, obs_xy, X_all, U_all, cost_all, viol_all, mem, stream);
+}
+int igt_rollout_batch_f64(igt_handle* h, int32_t B, const double* x0, const double* u_prev, const double* kparams,
+                          const uint32_t* flags, const double* obs_xy, const double* tv_sv, const double* enc,
+                          double* X_all, double* U_all, double* cost_all, uint32_t* viol_all, int mem, void* stream) {
+    (void)tv_sv; (void)enc;
+    return rollout_impl<double>(h, B, x0, u_prev, kparams, flags, obs_xy, X_all, U_all, cost_all, viol_all, mem, stream);
+}
+
+int igt_cartesian_euler_f32(igt_handle* h, int32_t n, int32_t T, const float* z0, const float* u, float* z_out,
+                            int mem, void* stream) {
+    return cartesian_impl<float>(h, n, T, z0, u, z_out, mem, stream);
+}
+int igt_cartesian_euler_f64(igt_handle* h, int32_t n, int32_t T, const double* z0, const double* u, double* z_out,
+                            int mem, void* stream) {
+    return cartesian_impl<double>(h, n, T, z0, u, z_out, mem, stream);
+}
+
+int igt_set_profiling(igt_handle* h, int enable) {
+    if (!h) return fail(IGT_E_INVALID, "null handle");
+    h->prof = enable != 0;
+    h->ev_recorded = false;
+    return IGT_OK;
+}
+
+int igt_get_kernel_ms(igt_handle* h, float* search_ms, float* emit_ms) {
+    if (!h) return fail(IGT_E_INVALID, "null handle");
+    if (!h->prof || !h->ev_recorded) return fail(IGT_E_STATE, "no profiled solve recorded");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventSynchronize(h->ev[2]));
+    float a = 0, b = 0;
+    HIPCHK(hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+    HIPCHK(hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+    if (search_ms) *search_ms = a;
+    if (emit_ms) *emit_ms = b;
+    return IGT_OK;
+}
+
+int igt_algorithmic_bytes_per_solve(const igt_handle* h, int elem_size, int64_t* read_bytes, int64_t* write_bytes) {
+    if (!h) return fail(IGT_E_INVALID, "null handle");
+    if (elem_size != 4 && elem_size != 8) return fail(IGT_E_INVALID, "elem_size must be 4 or 8");
+    const igt_params& p = h->p;
+    int64_t r = (int64_t)(7 + 2 + 3) * elem_size + 4 + (int64_t)p.n_obs * 2 * (p.N + 1) * elem_size;
+    if (p.cost_mode == IGT_COST_VALUE_NET) r += 4 * elem_size;
+    const int64_t w = (int64_t)(7 * (p.N + 1) + 2 * p.N) * elem_size + elem_size + 4 + 4;
+    if (read_bytes) *read_bytes = r;
+    if (write_bytes) *write_bytes = w;
+    return IGT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,427 @@
+// igt_device.h -- device-side arithmetic of the batched shooting solver (gfx950).
+//
+// Mapping: one 64-lane wavefront owns one scenario; lane l rolls
+// candidates l, l+64, l+128, ... (NC of them interleaved in registers per pass), so every
+// per-scenario input is wave-uniform and lives in SGPRs, the recurrence over the horizon
+// runs in VGPRs, and the arg-min over candidates is one 6-step wave butterfly.
+//
+// Two steppers implement one control step of the reference's RK4 Frenet bicycle model
+// (kinematic_bicycle_model_frenet.py:70-127; casadi twin 129-185 used by mpc.py:201-209):
+//   ExactStepper<T> : operation-for-operation what the reference / the float64 oracle does.
+//   FastStepper     : float derivatives + double state accumulators, stage angles by
+//                     rotating the sub-step's (sin,cos) through the small stage offsets.
+// Cost (mpc.py:356-373) and constraints (mpc.py:177-180, 223-226, 296-321) are evaluated
+// in double on the step-boundary states by Bookkeeper, shared by both steppers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace igt {
+
+struct KP {  // kernel parameters (by value -> SGPRs)
+    int N, n_rk4, C, n_obs, cand_mode, cost_mode, F, G;
+    double dt, h, l_r, lr_ratio, v_min, v_max, a_min, a_max, df_max;
+    double rate_a, rate_df, ey_lim, dmin2, w_u, tol;
+};
+
+enum { CAND_LATTICE = 0, CAND_TABLE = 1 };
+enum { VIOL_BOX_V = 1, VIOL_BOX_U = 2, VIOL_RATE = 4, VIOL_EY = 8, VIOL_TERMINAL = 16,
+       VIOL_COLLISION = 32, VIOL_NONFINITE = 64 };
+
+// ---------------------------------------------------------------------------------------
+// candidate control sequences (always generated in double so that u_out is the oracle's U)
+// ---------------------------------------------------------------------------------------
+struct Ctl {
+    double a, df;        // last generated control
+    double da, ddf;      // lattice increments
+};
+
+__device__ __forceinline__ double clampd(double x, double lo, double hi) {
+    return fmin(fmax(x, lo), hi);
+}
+
+__device__ __forceinline__ void ctl_init(Ctl& c, const KP& P, int idx, double a_prev, double df_prev) {
+    c.a = a_prev;
+    c.df = df_prev;
+    const int i = idx / P.G, j = idx - i * P.G;
+    // da_i = -ra + (2 ra) i / (G-1)   (oracle candidates_lattice)
+    c.da = -P.rate_a + (2 * P.rate_a) * (double)i / (double)(P.G - 1);
+    c.ddf = -P.rate_df + (2 * P.rate_df) * (double)j / (double)(P.G - 1);
+}
+
+// advances to step k; returns violation bits for the input box / rate constraints
+__device__ __forceinline__ unsigned ctl_step(Ctl& c, const KP& P, int idx, int k,
+                                             const double* __restrict__ table) {
+    unsigned v = 0;
+    if (P.cand_mode == CAND_TABLE) {
+        const double a = table[((size_t)idx * 2 + 0) * P.N + k];
+        const double d = table[((size_t)idx * 2 + 1) * P.N + k];
+        // input-rate constraints, mpc.py:301-312 (u_{-1} = u_prev)
+        if (fmax(fabs(a - c.a) - P.rate_a, fabs(d - c.df) - P.rate_df) > P.tol) v |= VIOL_RATE;
+        c.a = a;
+        c.df = d;
+    } else {
+        c.a = clampd(c.a + c.da, P.a_min, P.a_max);
+        c.df = clampd(c.df + c.ddf, -P.df_max, P.df_max);
+    }
+    // input box, mpc.py:318-321
+    if (fmax(fmax(P.a_min - c.a, c.a - P.a_max), fmax(-P.df_max - c.df, c.df - P.df_max)) > P.tol)
+        v |= VIOL_BOX_U;
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// ExactStepper<T>: the oracle's arithmetic in type T
+// ---------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void sincos_t(T x, T* s, T* c);
+template <> __device__ __forceinline__ void sincos_t<double>(double x, double* s, double* c) { sincos(x, s, c); }
+template <> __device__ __forceinline__ void sincos_t<float>(float x, float* s, float* c) { sincosf(x, s, c); }
+template <typename T> __device__ __forceinline__ T tan_t(T x);
+template <> __device__ __forceinline__ double tan_t<double>(double x) { return tan(x); }
+template <> __device__ __forceinline__ float tan_t<float>(float x) { return tanf(x); }
+template <typename T> __device__ __forceinline__ T atan_t(T x);
+template <> __device__ __forceinline__ double atan_t<double>(double x) { return atan(x); }
+template <> __device__ __forceinline__ float atan_t<float>(float x) { return atanf(x); }
+
+template <typename T>
+struct ExactStepper {
+    struct State { T x, y, s, ey, ep, v, psi; };
+    struct Beta { T beta, sinb; };
+    T h, hh, h6, l_r, lr_ratio, b0, b1, kv;
+    int n_rk4;
+
+    __device__ __forceinline__ void init(const KP& P, double b0_, double b1_, double kv_) {
+        h = (T)P.h; hh = h / 2; h6 = h / 6;
+        l_r = (T)P.l_r; lr_ratio = (T)P.lr_ratio;
+        b0 = (T)b0_; b1 = (T)b1_; kv = (T)kv_;
+        n_rk4 = P.n_rk4;
+    }
+    __device__ __forceinline__ void set(State& st, const double (&x0)[7]) const {
+        st.x = (T)x0[0]; st.y = (T)x0[1]; st.s = (T)x0[2]; st.ey = (T)x0[3];
+        st.ep = (T)x0[4]; st.v = (T)x0[5]; st.psi = (T)x0[6];
+    }
+    __device__ __forceinline__ void get(const State& st, double (&o)[7]) const {
+        o[0] = st.x; o[1] = st.y; o[2] = st.s; o[3] = st.ey; o[4] = st.ep; o[5] = st.v; o[6] = st.psi;
+    }
+    __device__ __forceinline__ Beta prep(double df) const {
+        Beta b;
+        b.beta = atan_t<T>(lr_ratio * tan_t<T>((T)df));          // frenet.py:72
+        T c;
+        sincos_t<T>(b.beta, &b.sinb, &c);
+        return b;
+    }
+    // derivative in the reference's order [s, ey, epsi, v, x, y, psi] (frenet.py:108)
+    __device__ __forceinline__ void deriv(T s, T ey, T ep, T v, T psi, T a, const Beta& B, T (&k)[7]) const {
+        const T K = (s >= b0 ? kv : (T)0) - (s >= b1 ? kv : (T)0);  // mpc.py:199 pw_const
+        T sn, cs;
+        sincos_t<T>(B.beta + ep, &sn, &cs);
+        k[0] = v * cs / ((T)1 - K * ey);                            // :73
+        k[1] = v * sn;                                              // :76
+        const T w = v * B.sinb / l_r;                               // :90
+        k[2] = w - k[0] * K;                                        // :79
+        k[3] = a;                                                   // :81
+        T s2, c2;
+        sincos_t<T>(psi + B.beta, &s2, &c2);
+        k[4] = v * c2;                                              // :84
+        k[5] = v * s2;                                              // :87
+        k[6] = w;
+    }
+    __device__ __forceinline__ void step(State& st, double a_, const Beta& B) const {
+        const T a = (T)a_;
+        T s = st.s, ey = st.ey, ep = st.ep, v = st.v, x = st.x, y = st.y, psi = st.psi;
+        for (int j = 0; j < n_rk4; ++j) {                           // :107
+            T k1[7], k2[7], k3[7], k4[7];
+            deriv(s, ey, ep, v, psi, a, B, k1);
+            deriv(s + hh * k1[0], ey + hh * k1[1], ep + hh * k1[2], v + hh * k1[3], psi + hh * k1[6], a, B, k2);
+            deriv(s + hh * k2[0], ey + hh * k2[1], ep + hh * k2[2], v + hh * k2[3], psi + hh * k2[6], a, B, k3);
+            // reference quirk kept: k4's x,y rows see psi + h/2*k3[6]      (:111)
+            deriv(s + h * k3[0], ey + h * k3[1], ep + h * k3[2], v + h * k3[3], psi + hh * k3[6], a, B, k4);
+            s = s + h6 * (k1[0] + 2 * k2[0] + 2 * k3[0] + k4[0]);     // :113
+            ey = ey + h6 * (k1[1] + 2 * k2[1] + 2 * k3[1] + k4[1]);
+            ep = ep + h6 * (k1[2] + 2 * k2[2] + 2 * k3[2] + k4[2]);
+            v = v + h6 * (k1[3] + 2 * k2[3] + 2 * k3[3] + k4[3]);
+            x = x + h6 * (k1[4] + 2 * k2[4] + 2 * k3[4] + k4[4]);
+            y = y + h6 * (k1[5] + 2 * k2[5] + 2 * k3[5] + k4[5]);
+            psi = psi + h6 * (k1[6] + 2 * k2[6] + 2 * k3[6] + k4[6]);
+        }
+        st.s = s; st.ey = ey; st.ep = ep; st.v = v; st.x = x; st.y = y; st.psi = psi;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// FastStepper: the same RK4 stages with float derivatives.
+//   * state accumulators are double (80 float-rounded increments would otherwise random-walk
+//     to ~1e-5 in s/x/y); every stage ARGUMENT is "base + small offset":
+//       - curvature switch K(s') is decided on float(s - b) + offset, i.e. relative to the
+//         break-point, so the comparison is exact to ~1e-9 near the switch;
+//       - sin/cos of (beta+epsi') and (psi'+beta) come from rotating the sub-step's base
+//         (sin,cos) by the offset with a short polynomial (|offset| <= h*|rate| << 1);
+//         the base pair is refreshed with sincosf once per control step.
+//   * psi and v are not coupled back, so their stage values are closed-form:
+//       v_j = v + c_j a,   psi'_j = psi + (h/2) v_{j-1} sin(beta)/l_r  (quirk :111 included)
+//     and the x,y rows collapse to one rotation of (A,B) = sum w_j v_j (cos,sin)(offset_j).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void small_sincos(float d, float& sd, float& cd) {
+    // |d| <= 0.5: truncation <= 2e-9 (sin), 3e-10 (cos)
+    const float d2 = d * d;
+    float p = fmaf(d2, -1.0f / 5040.0f, 1.0f / 120.0f);
+    p = fmaf(d2, p, -1.0f / 6.0f);
+    sd = fmaf(d * d2, p, d);
+    float q = fmaf(d2, 1.0f / 40320.0f, -1.0f / 720.0f);
+    q = fmaf(d2, q, 1.0f / 24.0f);
+    q = fmaf(d2, q, -0.5f);
+    cd = fmaf(d2, q, 1.0f);
+}
+
+__device__ __forceinline__ void rotate(float& s, float& c, float sd, float cd) {
+    const float s_ = fmaf(s, cd, c * sd);
+    const float c_ = fmaf(c, cd, -(s * sd));
+    s = s_; c = c_;
+}
+
+// sin/cos of a double angle: float sincosf on the rounded angle + first-order residual
+__device__ __forceinline__ void sincos_hi_lo(double ang, float& s, float& c) {
+    const float hi = (float)ang;
+    const float lo = (float)(ang - (double)hi);
+    float sh, ch;
+    sincosf(hi, &sh, &ch);
+    s = fmaf(ch, lo, sh);
+    c = fmaf(-sh, lo, ch);
+}
+
+struct FastStepper {
+    struct State { double x, y, s, ey, ep, v, psi; };
+    struct Beta { float cb, sb, sblr; };
+    float h, hh, h6, kv, inv_lr, lr_ratio;
+    double b0, b1, hd;
+    int n_rk4;
+
+    __device__ __forceinline__ void init(const KP& P, double b0_, double b1_, double kv_) {
+        h = (float)P.h; hh = (float)(P.h / 2); h6 = (float)(P.h / 6);
+        hd = P.h;
+        kv = (float)kv_; inv_lr = (float)(1.0 / P.l_r); lr_ratio = (float)P.lr_ratio;
+        b0 = b0_; b1 = b1_;
+        n_rk4 = P.n_rk4;
+    }
+    __device__ __forceinline__ void set(State& st, const double (&x0)[7]) const {
+        st.x = x0[0]; st.y = x0[1]; st.s = x0[2]; st.ey = x0[3]; st.ep = x0[4]; st.v = x0[5]; st.psi = x0[6];
+    }
+    __device__ __forceinline__ void get(const State& st, double (&o)[7]) const {
+        o[0] = st.x; o[1] = st.y; o[2] = st.s; o[3] = st.ey; o[4] = st.ep; o[5] = st.v; o[6] = st.psi;
+    }
+    __device__ __forceinline__ Beta prep(double df) const {
+        // beta = atan(t), t = l_r/(l_f+l_r) tan(df)  ->  cos(beta) = 1/sqrt(1+t^2), sin(beta) = t cos(beta)
+        const float t = lr_ratio * tanf((float)df);
+        Beta B;
+        B.cb = rsqrtf(fmaf(t, t, 1.0f));
+        B.sb = t * B.cb;
+        B.sblr = B.sb * inv_lr;
+        return B;
+    }
+    __device__ __forceinline__ float curv(float d0, float d1) const {
+        return (d0 >= 0.0f ? kv : 0.0f) - (d1 >= 0.0f ? kv : 0.0f);
+    }
+    __device__ __forceinline__ void step(State& st, double a_, const Beta& B) const {
+        const float a = (float)a_;
+        // base (sin,cos) of theta1 = beta+epsi and theta2 = psi+beta at the control-step start
+        float s1, c1, s2, c2;
+        sincos_hi_lo(st.ep, s1, c1);
+        rotate(s1, c1, B.sb, B.cb);
+        sincos_hi_lo(st.psi, s2, c2);
+        rotate(s2, c2, B.sb, B.cb);
+        const float ha = hh * a;
+        for (int j = 0; j < n_rk4; ++j) {
+            const float v1 = (float)st.v;
+            const float ey0 = (float)st.ey;
+            const float d0 = (float)(st.s - b0);
+            const float d1 = (float)(st.s - b1);
+            const float v2 = v1 + ha;          // stages 2,3
+            const float v4 = v2 + ha;          // stage 4
+            // ---- stage 1
+            float K = curv(d0, d1);
+            float ds1 = v1 * c1 * __builtin_amdgcn_rcpf(fmaf(-K, ey0, 1.0f));
+            float de1 = v1 * s1;
+            const float w1 = v1 * B.sblr;
+            float dp1 = fmaf(-ds1, K, w1);
+            // ---- stage 2 (arguments base + h/2 k1)
+            float sd, cd, sa, ca;
+            small_sincos(hh * dp1, sd, cd);
+            sa = s1; ca = c1; rotate(sa, ca, sd, cd);
+            float o = hh * ds1;
+            K = curv(d0 + o, d1 + o);
+            float ds2 = v2 * ca * __builtin_amdgcn_rcpf(fmaf(-K, fmaf(hh, de1, ey0), 1.0f));
+            float de2 = v2 * sa;
+            const float w2 = v2 * B.sblr;
+            float dp2 = fmaf(-ds2, K, w2);
+            // ---- stage 3 (base + h/2 k2)
+            small_sincos(hh * dp2, sd, cd);
+            sa = s1; ca = c1; rotate(sa, ca, sd, cd);
+            o = hh * ds2;
+            K = curv(d0 + o, d1 + o);
+            float ds3 = v2 * ca * __builtin_amdgcn_rcpf(fmaf(-K, fmaf(hh, de2, ey0), 1.0f));
+            float de3 = v2 * sa;
+            float dp3 = fmaf(-ds3, K, w2);
+            // ---- stage 4 (base + h k3)
+            small_sincos(h * dp3, sd, cd);
+            sa = s1; ca = c1; rotate(sa, ca, sd, cd);
+            o = h * ds3;
+            K = curv(d0 + o, d1 + o);
+            float ds4 = v4 * ca * __builtin_amdgcn_rcpf(fmaf(-K, fmaf(h, de3, ey0), 1.0f));
+            float de4 = v4 * sa;
+            const float w4 = v4 * B.sblr;
+            float dp4 = fmaf(-ds4, K, w4);
+            // ---- Cartesian rows: psi offsets are h/2 w1 (stage 2) and h/2 w2 (stages 3 AND 4, :111)
+            float sd2, cd2, sd3, cd3;
+            small_sincos(hh * w1, sd2, cd2);
+            small_sincos(hh * w2, sd3, cd3);
+            const float v34 = fmaf(2.0f, v2, v4);
+            const float A = fmaf(v34, cd3, fmaf(2.0f * v2, cd2, v1));
+            const float Bq = fmaf(v34, sd3, 2.0f * v2 * sd2);
+            const float dx = fmaf(c2, A, -(s2 * Bq));
+            const float dy = fmaf(s2, A, c2 * Bq);
+            // ---- combine (frenet.py:113-119)
+            const float is = h6 * (ds1 + 2.0f * ds2 + 2.0f * ds3 + ds4);
+            const float ie = h6 * (de1 + 2.0f * de2 + 2.0f * de3 + de4);
+            const float ip = h6 * (dp1 + 2.0f * dp2 + 2.0f * dp3 + dp4);
+            const float iw = h6 * (w1 + 4.0f * w2 + w4);
+            st.s += (double)is;
+            st.ey += (double)ie;
+            st.ep += (double)ip;
+            st.psi += (double)iw;
+            st.x += (double)(h6 * dx);
+            st.y += (double)(h6 * dy);
+            st.v = fma(hd, a_, st.v);
+            // base angles for the next sub-step
+            small_sincos(ip, sd, cd);
+            rotate(s1, c1, sd, cd);
+            small_sincos(iw, sd, cd);
+            rotate(s2, c2, sd, cd);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// Bookkeeper: cost (mpc.py:356-373) and constraint verdicts on the step-boundary states
+// ---------------------------------------------------------------------------------------
+struct Book {
+    double J;
+    double s0;
+    unsigned viol;
+};
+
+__device__ __forceinline__ void book_state(Book& bk, const KP& P, int k, const double (&st)[7],
+                                           const double* __restrict__ obs /* scenario's [n_obs,2,N+1] */,
+                                           bool obs_is_float) {
+    // tracking terms, mpc.py:363-364 (epsi first, then ey)
+    bk.J = bk.J + st[4] * st[4];
+    bk.J = bk.J + st[3] * st[3];
+    // |ey_k| <= ey_lim, k = 0..N (mpc.py:296-299)
+    if (fabs(st[3]) - P.ey_lim > P.tol) bk.viol |= VIOL_EY;
+    // 0 <= v_k <= v_max, k = 0..N-1 (mpc.py:315-317)
+    if (k < P.N && fmax(P.v_min - st[5], st[5] - P.v_max) > P.tol) bk.viol |= VIOL_BOX_V;
+    // non-finite guard
+    if (!(fabs(st[0]) < 1e300 && fabs(st[1]) < 1e300 && fabs(st[2]) < 1e300 && fabs(st[3]) < 1e300 &&
+          fabs(st[4]) < 1e300 && fabs(st[6]) < 1e300))
+        bk.viol |= VIOL_NONFINITE;
+    (void)obs; (void)obs_is_float;
+}
+
+template <typename T>
+__device__ __forceinline__ unsigned collision_viol(const KP& P, int k, double x, double y,
+                                                   const T* __restrict__ obs) {
+    // d_min^2 - |p_k - p_obs,k|^2 <= 0 for k = 1..N (mpc.py:223-226)
+    unsigned v = 0;
+    for (int o = 0; o < P.n_obs; ++o) {
+        const double ox = (double)obs[(o * 2 + 0) * (P.N + 1) + k];
+        const double oy = (double)obs[(o * 2 + 1) * (P.N + 1) + k];
+        const double dx = x - ox, dy = y - oy;
+        if (P.dmin2 - (dx * dx + dy * dy) > P.tol) v |= VIOL_COLLISION;
+    }
+    return v;
+}
+
+__device__ __forceinline__ unsigned terminal_viol(const KP& P, double v, double a,
+                                                  const double* __restrict__ cinf /* [F,3] = A0,A1,b */) {
+    // C_inf.A [v_{N-1}; a_{N-1}] <= C_inf.b   (mpc.py:177-180)
+    double worst = -1e300;
+    for (int m = 0; m < P.F; ++m) {
+        const double t = cinf[m * 3 + 0] * v + cinf[m * 3 + 1] * a - cinf[m * 3 + 2];
+        worst = fmax(worst, t);
+    }
+    return (P.F > 0 && worst > P.tol) ? (unsigned)VIOL_TERMINAL : 0u;
+}
+
+// ---------------------------------------------------------------------------------------
+// one rollout pass over NC candidates of one scenario
+// ---------------------------------------------------------------------------------------
+template <typename T>
+struct Scenario {           // wave-uniform inputs of one scenario
+    double x0[7];
+    double a_prev, df_prev;
+    double b0, b1, kv;
+    const T* obs;           // [n_obs, 2, N+1]
+};
+
+struct NullSink {
+    __device__ __forceinline__ void ctrl(int, int, double, double) {}
+    __device__ __forceinline__ void state(int, int, const double (&)[7]) {}
+};
+
+template <class Stepper, int NC, bool SHARED_DF, typename T, class Sink>
+__device__ __forceinline__ void rollout_pass(const KP& P, const Scenario<T>& S, const int (&cidx)[NC],
+                                             const double* __restrict__ table,
+                                             const double* __restrict__ cinf, Sink& sink,
+                                             double (&Jout)[NC], unsigned (&vout)[NC],
+                                             double (&sN)[NC], double (&vN)[NC]) {
+    Stepper stp;
+    stp.init(P, S.b0, S.b1, S.kv);
+    typename Stepper::State st[NC];
+    Ctl ctl[NC];
+    Book bk[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        stp.set(st[q], S.x0);
+        ctl_init(ctl[q], P, cidx[q], S.a_prev, S.df_prev);
+        bk[q].J = 0.0;
+        bk[q].s0 = S.x0[2];
+        bk[q].viol = 0;
+        sink.state(q, 0, S.x0);
+    }
+    for (int k = 0; k < P.N; ++k) {
+        typename Stepper::Beta B[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            bk[q].viol |= ctl_step(ctl[q], P, cidx[q], k, table);
+            sink.ctrl(q, k, ctl[q].a, ctl[q].df);
+            // control effort first, then the tracking terms of state k (mpc.py:361-364)
+            bk[q].J = bk[q].J + P.w_u * (ctl[q].a * ctl[q].a + ctl[q].df * ctl[q].df);
+            double cur[7];
+            stp.get(st[q], cur);
+            book_state(bk[q], P, k, cur, nullptr, false);
+            if (k >= 1) bk[q].viol |= collision_viol<T>(P, k, cur[0], cur[1], S.obs);
+            if (k == P.N - 1) bk[q].viol |= terminal_viol(P, cur[5], ctl[q].a, cinf);
+            if (!SHARED_DF || q == 0) B[q] = stp.prep(ctl[q].df);
+        }
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            stp.step(st[q], ctl[q].a, B[SHARED_DF ? 0 : q]);
+            double nxt[7];
+            stp.get(st[q], nxt);
+            sink.state(q, k + 1, nxt);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        double cur[7];
+        stp.get(st[q], cur);
+        book_state(bk[q], P, P.N, cur, nullptr, false);
+        bk[q].viol |= collision_viol<T>(P, P.N, cur[0], cur[1], S.obs);
+        sN[q] = cur[2];
+        vN[q] = cur[5];
+        // terminal progress term, mpc.py:372 (the value-net variant subtracts V instead, :369)
+        Jout[q] = bk[q].J;
+        vout[q] = bk[q].viol;
+    }
+}
+
+}  // namespace igt

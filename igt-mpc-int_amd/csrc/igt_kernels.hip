@@ -1,0 +1,253 @@
+// igt_kernels.hip -- gfx950 kernels of the batched shooting solver and their launchers.
+//
+//   search_kernel   one wavefront per scenario: rolls all C candidates (NC per lane per pass),
+//                   cost + verdicts, lane-local best, 6-step wave butterfly arg-min,
+//                   writes (cost, argmin, status) = 12 B per solve.
+//   emit_kernel     one lane per scenario: re-rolls the winner with the same arithmetic and
+//                   writes x*[7,N+1], u*[2,N] (1/C of the search work).
+//   rollout_all_kernel   debug/parity: every candidate's trajectory, cost and verdict bits.
+//   cartesian_euler_kernel   kinematic_bicycle_model.py:15-50, one lane per trajectory.
+#include "igt_device.h"
+#include "igt_launch.h"
+
+namespace igt {
+
+template <typename T>
+__device__ __forceinline__ void load_scenario(Scenario<T>& S, const KP& P, int b, const T* __restrict__ x0,
+                                              const T* __restrict__ u_prev, const T* __restrict__ kparams,
+                                              const uint32_t* __restrict__ flags, const T* __restrict__ obs) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) S.x0[i] = (double)x0[(size_t)b * 7 + i];
+    // ego routes '32','41' use |heading| (mpc.py:231-234, 282-285)
+    if (flags[b] & 1u) S.x0[6] = fabs(S.x0[6]);
+    S.a_prev = (double)u_prev[(size_t)b * 2 + 0];
+    S.df_prev = (double)u_prev[(size_t)b * 2 + 1];
+    S.b0 = (double)kparams[(size_t)b * 3 + 0];
+    S.b1 = (double)kparams[(size_t)b * 3 + 1];
+    S.kv = (double)kparams[(size_t)b * 3 + 2];
+    S.obs = obs + (size_t)b * P.n_obs * 2 * (P.N + 1);
+}
+
+__device__ __forceinline__ bool finite_d(double x) { return fabs(x) < 1.79e308; }
+
+template <class Stepper, typename T, int NC, bool SHARED_DF>
+__global__ __launch_bounds__(256) void search_kernel(KP P, int B, const T* __restrict__ x0,
+                                                     const T* __restrict__ u_prev,
+                                                     const T* __restrict__ kparams,
+                                                     const uint32_t* __restrict__ flags,
+                                                     const T* __restrict__ obs,
+                                                     const double* __restrict__ table,
+                                                     const double* __restrict__ cinf,
+                                                     T* __restrict__ cost_out, int32_t* __restrict__ argmin_out,
+                                                     int32_t* __restrict__ status_out) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;  // wave-uniform
+    const int lane = threadIdx.x & 63;
+    Scenario<T> S;
+    load_scenario<T>(S, P, b, x0, u_prev, kparams, flags, obs);
+
+    double bestJ = 0.0;
+    int bestC = -1;
+    NullSink sink;
+    const int passes = P.C / (64 * NC);
+    for (int p = 0; p < passes; ++p) {
+        int cidx[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) cidx[q] = (p * NC + q) * 64 + lane;
+        double J[NC], sN[NC], vN[NC];
+        unsigned viol[NC];
+        rollout_pass<Stepper, NC, SHARED_DF, T>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const double Jq = J[q] - (sN[q] - S.x0[2]);  // mpc.py:372
+            const bool ok = (viol[q] == 0) && finite_d(Jq);
+            // candidates arrive in increasing index per lane: strict '<' keeps the lowest index
+            if (ok && (bestC < 0 || Jq < bestJ)) { bestJ = Jq; bestC = cidx[q]; }
+        }
+    }
+    // wave butterfly arg-min, ties -> lowest candidate index
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double oJ = __shfl_xor(bestJ, off, 64);
+        const int oC = __shfl_xor(bestC, off, 64);
+        const bool take = (oC >= 0) && (bestC < 0 || oJ < bestJ || (oJ == bestJ && oC < bestC));
+        if (take) { bestJ = oJ; bestC = oC; }
+    }
+    if (lane == 0) {
+        cost_out[b] = bestC >= 0 ? (T)bestJ : (T)INFINITY;
+        argmin_out[b] = bestC;
+        status_out[b] = bestC >= 0 ? 0 : 1;
+    }
+}
+
+template <typename T>
+struct StoreSink {
+    T* x;   // [7, N+1] of this scenario/candidate (may be null)
+    T* u;   // [2, N]
+    int N;
+    __device__ __forceinline__ void ctrl(int, int k, double a, double df) {
+        if (u) { u[k] = (T)a; u[N + k] = (T)df; }
+    }
+    __device__ __forceinline__ void state(int, int k, const double (&st)[7]) {
+        if (x) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) x[i * (N + 1) + k] = (T)st[i];
+        }
+    }
+};
+
+template <class Stepper, typename T>
+__global__ __launch_bounds__(64) void emit_kernel(KP P, int B, const T* __restrict__ x0,
+                                                  const T* __restrict__ u_prev, const T* __restrict__ kparams,
+                                                  const uint32_t* __restrict__ flags, const T* __restrict__ obs,
+                                                  const double* __restrict__ table,
+                                                  const double* __restrict__ cinf,
+                                                  const int32_t* __restrict__ argmin, T* __restrict__ x_out,
+                                                  T* __restrict__ u_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    T* xo = x_out + (size_t)b * 7 * (P.N + 1);
+    T* uo = u_out + (size_t)b * 2 * P.N;
+    const int c = argmin[b];
+    if (c < 0) {  // is_opt False (mpc.py:402-406): no trajectory
+        const T nan = (T)NAN;
+        for (int i = 0; i < 7 * (P.N + 1); ++i) xo[i] = nan;
+        for (int i = 0; i < 2 * P.N; ++i) uo[i] = nan;
+        return;
+    }
+    Scenario<T> S;
+    load_scenario<T>(S, P, b, x0, u_prev, kparams, flags, obs);
+    StoreSink<T> sink{xo, uo, P.N};
+    const int cidx[1] = {c};
+    double J[1], sN[1], vN[1];
+    unsigned viol[1];
+    rollout_pass<Stepper, 1, false, T>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
+}
+
+template <class Stepper, typename T>
+__global__ __launch_bounds__(256) void rollout_all_kernel(KP P, int B, const T* __restrict__ x0,
+                                                          const T* __restrict__ u_prev,
+                                                          const T* __restrict__ kparams,
+                                                          const uint32_t* __restrict__ flags,
+                                                          const T* __restrict__ obs,
+                                                          const double* __restrict__ table,
+                                                          const double* __restrict__ cinf, T* __restrict__ X_all,
+                                                          T* __restrict__ U_all, T* __restrict__ cost_all,
+                                                          uint32_t* __restrict__ viol_all) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    Scenario<T> S;
+    load_scenario<T>(S, P, b, x0, u_prev, kparams, flags, obs);
+    for (int c = lane; c < P.C; c += 64) {
+        const size_t bc = (size_t)b * P.C + c;
+        StoreSink<T> sink{X_all ? X_all + bc * 7 * (P.N + 1) : nullptr, U_all ? U_all + bc * 2 * P.N : nullptr, P.N};
+        const int cidx[1] = {c};
+        double J[1], sN[1], vN[1];
+        unsigned viol[1];
+        rollout_pass<Stepper, 1, false, T>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
+        const double Jq = J[0] - (sN[0] - S.x0[2]);
+        if (!finite_d(Jq)) viol[0] |= VIOL_NONFINITE;
+        cost_all[bc] = (T)Jq;
+        viol_all[bc] = viol[0];
+    }
+}
+
+// kinematic_bicycle_model.py:27-31, T steps per trajectory
+template <typename T>
+__global__ __launch_bounds__(256) void cartesian_euler_kernel(int n, int steps, T dt, T l_r, T l_f,
+                                                              const T* __restrict__ z0, const T* __restrict__ u,
+                                                              T* __restrict__ z_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    T x = z0[(size_t)i * 4 + 0], y = z0[(size_t)i * 4 + 1], psi = z0[(size_t)i * 4 + 2], v = z0[(size_t)i * 4 + 3];
+    T* zo = z_out + (size_t)i * 4 * (steps + 1);
+    zo[0] = x; zo[steps + 1] = y; zo[2 * (steps + 1)] = psi; zo[3 * (steps + 1)] = v;
+    const T ratio = l_r / (l_f + l_r);
+    for (int k = 0; k < steps; ++k) {
+        const T a = u[((size_t)i * 2 + 0) * steps + k];
+        const T df = u[((size_t)i * 2 + 1) * steps + k];
+        const T tdf = tan_t<T>(df);
+        const T beta = atan_t<T>(ratio * tdf);                          // :27
+        T sb, cb, s2, c2;
+        sincos_t<T>(beta, &sb, &cb);
+        sincos_t<T>(psi + beta, &s2, &c2);
+        const T xn = x + dt * v * c2;                                    // :28
+        const T yn = y + dt * v * s2;                                    // :29
+        const T pn = psi + dt * (v * cb / (l_r + l_f) * tdf);            // :30
+        const T vn = v + dt * a;                                         // :31
+        x = xn; y = yn; psi = pn; v = vn;
+        zo[k + 1] = x; zo[steps + 1 + k + 1] = y; zo[2 * (steps + 1) + k + 1] = psi; zo[3 * (steps + 1) + k + 1] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------
+template <class Stepper, typename T, int NC>
+static hipError_t launch_search_nc(const KP& P, int B, const SolveArgs<T>& A, hipStream_t st) {
+    const dim3 grid((B + 3) / 4), block(256);
+    if (P.cand_mode == CAND_LATTICE)
+        hipLaunchKernelGGL((search_kernel<Stepper, T, NC, true>), grid, block, 0, st, P, B, A.x0, A.u_prev, A.kparams,
+                           A.flags, A.obs, A.table, A.cinf, A.cost_out, A.argmin_out, A.status_out);
+    else
+        hipLaunchKernelGGL((search_kernel<Stepper, T, NC, false>), grid, block, 0, st, P, B, A.x0, A.u_prev, A.kparams,
+                           A.flags, A.obs, A.table, A.cinf, A.cost_out, A.argmin_out, A.status_out);
+    return hipGetLastError();
+}
+
+template <>
+hipError_t launch_search<float>(const KP& P, int B, const SolveArgs<float>& A, int nc, hipStream_t st) {
+    switch (nc) {
+        case 1: return launch_search_nc<FastStepper, float, 1>(P, B, A, st);
+        case 2: return launch_search_nc<FastStepper, float, 2>(P, B, A, st);
+        default: return launch_search_nc<FastStepper, float, 4>(P, B, A, st);
+    }
+}
+template <>
+hipError_t launch_search<double>(const KP& P, int B, const SolveArgs<double>& A, int nc, hipStream_t st) {
+    (void)nc;
+    return launch_search_nc<ExactStepper<double>, double, 1>(P, B, A, st);
+}
+
+template <>
+hipError_t launch_emit<float>(const KP& P, int B, const SolveArgs<float>& A, hipStream_t st) {
+    hipLaunchKernelGGL((emit_kernel<FastStepper, float>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, A.x0, A.u_prev,
+                       A.kparams, A.flags, A.obs, A.table, A.cinf, A.argmin_out, A.x_out, A.u_out);
+    return hipGetLastError();
+}
+template <>
+hipError_t launch_emit<double>(const KP& P, int B, const SolveArgs<double>& A, hipStream_t st) {
+    hipLaunchKernelGGL((emit_kernel<ExactStepper<double>, double>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, A.x0,
+                       A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.argmin_out, A.x_out, A.u_out);
+    return hipGetLastError();
+}
+
+template <>
+hipError_t launch_rollout_all<float>(const KP& P, int B, const SolveArgs<float>& A, float* X_all, float* U_all,
+                                     float* cost_all, uint32_t* viol_all, hipStream_t st) {
+    hipLaunchKernelGGL((rollout_all_kernel<FastStepper, float>), dim3((B + 3) / 4), dim3(256), 0, st, P, B, A.x0,
+                       A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, X_all, U_all, cost_all, viol_all);
+    return hipGetLastError();
+}
+template <>
+hipError_t launch_rollout_all<double>(const KP& P, int B, const SolveArgs<double>& A, double* X_all, double* U_all,
+                                      double* cost_all, uint32_t* viol_all, hipStream_t st) {
+    hipLaunchKernelGGL((rollout_all_kernel<ExactStepper<double>, double>), dim3((B + 3) / 4), dim3(256), 0, st, P, B,
+                       A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, X_all, U_all, cost_all, viol_all);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_cartesian(int n, int steps, double dt, double l_r, double l_f, const T* z0, const T* u, T* z_out,
+                            hipStream_t st) {
+    hipLaunchKernelGGL((cartesian_euler_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, st, n, steps, (T)dt, (T)l_r,
+                       (T)l_f, z0, u, z_out);
+    return hipGetLastError();
+}
+template hipError_t launch_cartesian<float>(int, int, double, double, double, const float*, const float*, float*, hipStream_t);
+template hipError_t launch_cartesian<double>(int, int, double, double, double, const double*, const double*, double*, hipStream_t);
+
+}  // namespace igt

@@ -1,0 +1,36 @@
+// igt_launch.h -- launcher declarations shared by igt_kernels.hip and igt_api.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "igt_device.h"
+
+namespace igt {
+
+template <typename T>
+struct SolveArgs {   // all device pointers
+    const T* x0;
+    const T* u_prev;
+    const T* kparams;
+    const uint32_t* flags;
+    const T* obs;
+    const T* tv_sv;
+    const T* enc;
+    const double* table;   // [C,2,N] or null
+    const double* cinf;    // [F,3] or null
+    T* x_out;
+    T* u_out;
+    T* cost_out;
+    int32_t* argmin_out;
+    int32_t* status_out;
+};
+
+template <typename T> hipError_t launch_search(const KP& P, int B, const SolveArgs<T>& A, int nc, hipStream_t st);
+template <typename T> hipError_t launch_emit(const KP& P, int B, const SolveArgs<T>& A, hipStream_t st);
+template <typename T>
+hipError_t launch_rollout_all(const KP& P, int B, const SolveArgs<T>& A, T* X_all, T* U_all, T* cost_all,
+                              uint32_t* viol_all, hipStream_t st);
+template <typename T>
+hipError_t launch_cartesian(int n, int steps, double dt, double l_r, double l_f, const T* z0, const T* u, T* z_out,
+                            hipStream_t st);
+
+}  // namespace igt

@@ -1,0 +1,90 @@
+"""ctypes binding of include/igtmpc.h (libigtmpc.so, built by csrc/Makefile).
+
+The product path has no CPU fallback: if the HIP library is missing or fails to
+load, importing a solver raises ImportError with the build command."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libigtmpc.so')
+
+IGT_MEM_DEVICE, IGT_MEM_HOST = 0, 1
+IGT_CAND_LATTICE, IGT_CAND_TABLE = 0, 1
+IGT_COST_PROGRESS, IGT_COST_VALUE_NET = 0, 1
+IGT_FLAG_ABS_HEADING = 1
+VIOL_BITS = dict(box_v=1, box_u=2, rate=4, ey=8, terminal=16, collision=32, nonfinite=64)
+
+
+class igt_params(C.Structure):
+    _fields_ = [('N', C.c_int32), ('n_rk4', C.c_int32), ('C', C.c_int32), ('n_obs', C.c_int32),
+                ('cand_mode', C.c_int32), ('cost_mode', C.c_int32),
+                ('dt', C.c_double), ('l_r', C.c_double), ('l_f', C.c_double),
+                ('v_min', C.c_double), ('v_max', C.c_double), ('a_min', C.c_double), ('a_max', C.c_double),
+                ('df_max', C.c_double), ('jerk_limit', C.c_double), ('steer_rate_limit', C.c_double),
+                ('ey_lim', C.c_double), ('d_min', C.c_double), ('w_u', C.c_double), ('feas_tol', C.c_double)]
+
+
+# every symbol include/igtmpc.h declares: name -> (restype, argtypes)
+_vp, _i32, _i = C.c_void_p, C.c_int32, C.c_int
+_SOLVE = [_vp, _i32] + [_vp] * 12 + [_i, _vp]
+_ROLL = [_vp, _i32] + [_vp] * 11 + [_i, _vp]
+_CART = [_vp, _i32, _i32, _vp, _vp, _vp, _i, _vp]
+SYMBOLS = {
+    'igt_version': (_i, []),
+    'igt_last_error': (C.c_char_p, []),
+    'igt_params_default': (_i, [C.POINTER(igt_params)]),
+    'igt_create': (_i, [C.POINTER(igt_params), _i, C.POINTER(_vp)]),
+    'igt_destroy': (_i, [_vp]),
+    'igt_get_params': (_i, [_vp, C.POINTER(igt_params)]),
+    'igt_set_cinf': (_i, [_vp, _vp, _vp, _i32]),
+    'igt_set_candidate_table': (_i, [_vp, _vp]),
+    'igt_set_value_net': (_i, [_vp, _i32, _vp, _vp, _vp, _vp, C.c_double, C.c_double]),
+    'igt_solve_batch_f32': (_i, _SOLVE),
+    'igt_solve_batch_f64': (_i, _SOLVE),
+    'igt_rollout_batch_f32': (_i, _ROLL),
+    'igt_rollout_batch_f64': (_i, _ROLL),
+    'igt_cartesian_euler_f32': (_i, _CART),
+    'igt_cartesian_euler_f64': (_i, _CART),
+    'igt_set_profiling': (_i, [_vp, _i]),
+    'igt_get_kernel_ms': (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    'igt_algorithmic_bytes_per_solve': (_i, [_vp, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libigtmpc.so once and sets every prototype.  Raises ImportError when the
+    library is absent -- there is deliberately no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                          f'or `make -C igt-mpc-int_amd/csrc`')
+    try:
+        # torch ships its own libamdhip64; it must be the first HIP runtime the process
+        # maps, otherwise a later `import torch` finds "No HIP GPUs" (two runtimes).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise ImportError(f'cannot load {LIB_PATH}: {e}') from e
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)     # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class IgtError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().igt_last_error()
+        raise IgtError(f'igtmpc error {rc}: {msg.decode() if msg else "?"}')

@@ -1,0 +1,196 @@
+/*
+ * igtmpc.h -- C ABI of the MI355X-native batched MPC rollout + shooting solver.
+ *
+ * The reference (hansungkim98122/IGT-MPC-INT) is pure Python and has NO FFI for
+ * this path: its boundary is the Python object API that evaluate.py consumes
+ * (MPC_Planner.update_initial_condition / update_predictions / solve,
+ * mpc.py:241-294, 383-406).  Each entry point below therefore cites the
+ * reference lines whose work it replaces; INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, caller-allocated buffers.
+ *   - every function returns 0 on success, <0 on error (IGT_E_*); the message is
+ *     available from igt_last_error() (thread-local).  Nothing throws.
+ *   - `mem` says where the caller's buffers live: IGT_MEM_DEVICE (HBM pointers,
+ *     work is enqueued on `stream` and the call returns without synchronising)
+ *     or IGT_MEM_HOST (the library stages through its own device buffers and
+ *     synchronises before returning).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the handle's own stream).
+ *   - state order everywhere: [x, y, s, ey, epsi, v, psi]      (mpc.py:163)
+ *   - array layouts are C-contiguous with the shapes written in the comments.
+ *   - one handle per (device, thread); handles share no mutable state.
+ */
+#ifndef IGTMPC_H
+#define IGTMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IGT_VERSION 100
+
+enum {
+    IGT_OK = 0,
+    IGT_E_INVALID = -1,   /* bad argument / unsupported parameter combination */
+    IGT_E_HIP = -2,       /* a HIP runtime call failed                        */
+    IGT_E_NOMEM = -3,
+    IGT_E_STATE = -4      /* e.g. value-net cost requested but no net loaded  */
+};
+
+enum { IGT_MEM_DEVICE = 0, IGT_MEM_HOST = 1 };
+
+/* candidate control-sequence families (build-defined: the reference's NLP has no
+ * candidates; SURVEY.md section 8d defines the lattice used for the benchmark) */
+enum {
+    IGT_CAND_LATTICE = 0,  /* G x G lattice of constant per-step (da, ddf) increments */
+    IGT_CAND_TABLE = 1,    /* explicit table U[C,2,N] shared by every scenario         */
+    IGT_CAND_RAMP_HOLD = 2 /* G x G: da_i held for the horizon; steering ramps at +/-rate
+                              towards one of G target angles and holds it             */
+};
+
+/* cost (mpc.py:356-373) */
+enum {
+    IGT_COST_PROGRESS = 0, /* ... - (s_N - s_0)                 eval_mode mpc,    mpc.py:372 */
+    IGT_COST_VALUE_NET = 1 /* ... - (V(Wn(x_N-mu))*sig + mu_t)  eval_mode gt_mpc, mpc.py:369 */
+};
+
+/* per-scenario flag bits (flags[B]) */
+#define IGT_FLAG_ABS_HEADING 1u /* ego route in {'32','41'}: psi_0 = |psi_0|  (mpc.py:231-234, 282-285) */
+
+/* violation bits reported by igt_rollout_batch_* (viol_out) */
+#define IGT_VIOL_BOX_V 1u      /* mpc.py:316-317  k = 0..N-1 */
+#define IGT_VIOL_BOX_U 2u      /* mpc.py:318-321            */
+#define IGT_VIOL_RATE 4u       /* mpc.py:301-312  (table candidates only; lattices satisfy it by construction) */
+#define IGT_VIOL_EY 8u         /* mpc.py:296-299  k = 0..N   */
+#define IGT_VIOL_TERMINAL 16u  /* mpc.py:177-180  C_inf * [v_{N-1}; a_{N-1}] <= b */
+#define IGT_VIOL_COLLISION 32u /* mpc.py:223-226  k = 1..N   */
+#define IGT_VIOL_NONFINITE 64u
+
+#define IGT_MAX_N 64
+#define IGT_MAX_CINF 256
+#define IGT_MAX_OBS 4
+
+typedef struct igt_handle igt_handle;
+
+/* The constants MPC_Planner.__init__ hard-codes (mpc.py:45-62) plus the
+ * discretisation (N, dt, n_rk4) and the candidate family. */
+typedef struct igt_params {
+    int32_t N;         /* horizon                      (mpc.py:38; evaluate.py:69)  */
+    int32_t n_rk4;     /* RK4 sub-steps per control step (evaluate.py:109 -> 4)     */
+    int32_t C;         /* candidates per solve; multiple of 64; lattices need C = G*G */
+    int32_t n_obs;     /* obstacles per scenario = M-1  (mpc.py:83)                 */
+    int32_t cand_mode; /* IGT_CAND_*  */
+    int32_t cost_mode; /* IGT_COST_*  */
+    double dt;         /* fourwayint.yaml:2  */
+    double l_r, l_f;   /* mpc.py:49-50       */
+    double v_min, v_max, a_min, a_max, df_max; /* mpc.py:57-62 */
+    double jerk_limit;       /* mpc.py:56 */
+    double steer_rate_limit; /* mpc.py:55 */
+    double ey_lim;           /* mpc.py:61 */
+    double d_min;            /* 2*ca_radius, mpc.py:45 */
+    double w_u;              /* 0.05, mpc.py:362 */
+    double feas_tol;         /* inequality verdicts are g <= feas_tol */
+} igt_params;
+
+/* Fills *p with the reference's numbers: N=20, dt=0.1, n_rk4=4, C=256, n_obs=1,
+ * lattice candidates, progress cost, mpc.py:45-62 limits, feas_tol=1e-6. */
+int igt_params_default(igt_params* p);
+
+const char* igt_last_error(void);
+int igt_version(void);
+
+/* Replaces MPC_Planner.__init__ (mpc.py:21-160) for a whole batch: no NLP is
+ * built; the handle owns a stream, staging buffers and the constant tables. */
+int igt_create(const igt_params* p, int device, igt_handle** out);
+int igt_destroy(igt_handle* h);
+int igt_get_params(const igt_handle* h, igt_params* out);
+
+/* Terminal set C_inf as half-planes A[F,2] * (v, a) <= b[F]
+ * (mpc.py:88-104 builds it with polytope; 177-180 applies it). F = 0 disables. */
+int igt_set_cinf(igt_handle* h, const double* A, const double* b, int32_t F);
+
+/* Explicit candidate table U[C,2,N] (row 0 = a_k, row 1 = df_k) for IGT_CAND_TABLE. */
+int igt_set_candidate_table(igt_handle* h, const double* U);
+
+/* Terminal value network (mpc.py:108-127, 367-369; model.py:14-51).
+ * n_layers Linear layers, dims[n_layers+1] = {6,128,...,1}; weights holds, per
+ * layer, W[out,in] row-major followed by b[out].  Wn[6,6], mu_f[6]: input
+ * whitening x -> Wn (x - mu_f); sigma_t, mu_t: target de-normalisation. */
+int igt_set_value_net(igt_handle* h, int32_t n_layers, const int32_t* dims, const double* weights,
+                      const double* Wn, const double* mu_f, double sigma_t, double mu_t);
+
+/* The batched solve.  Replaces, per scenario b, one
+ *   update_initial_condition (mpc.py:280-294) + update_predictions (241-278) + solve (383-406)
+ * of the reference by: generate C candidate control sequences from u_prev[b],
+ * roll each through the RK4 Frenet bicycle model
+ * (kinematic_bicycle_model_frenet.py:70-127 == mpc.py:201-209), evaluate the cost
+ * (mpc.py:356-373) and every constraint (mpc.py:177-180, 223-226, 296-321), and
+ * return the feasible arg-min (ties -> lowest candidate index).
+ *
+ *   x0      [B,7]              initial state                       (mpc.py:280-292)
+ *   u_prev  [B,2]              previously applied (a, df)          (mpc.py:286)
+ *   kparams [B,3]              curvature (b0, b1, Kv): K(s)=Kv on [b0,b1) else 0;
+ *                              straight routes pass (inf, inf, 0)  (mpc.py:183-200)
+ *   flags   [B]                IGT_FLAG_*
+ *   obs_xy  [B,n_obs,2,N+1]    obstacle x / y predictions, already passed through
+ *                              filter_preds (utils.py:365-388); k = 1..N are read
+ *   tv_sv   [B,2]  enc [B,2]   value-net cost only (may be NULL otherwise):
+ *                              (s,v) of the other vehicle's last raw prediction and
+ *                              (e_ego, e_tv) scenario encodings     (mpc.py:326-338)
+ *   x_out   [B,7,N+1]  u_out [B,2,N]   arg-min trajectory / controls (mpc.py:401)
+ *   cost_out[B]  argmin_out[B]  status_out[B]
+ *        status 0 <-> is_opt True; 1 <-> no feasible candidate (is_opt False,
+ *        mpc.py:402-406): then argmin = -1, cost = +inf, x_out/u_out = NaN.
+ *
+ * _f32: float storage, float derivatives, double state accumulators (the fast
+ *       path; within 1e-5*max(1,|ref|) of the float64 oracle).
+ * _f64: double everywhere, same operation order as the oracle (parity reference).
+ */
+int igt_solve_batch_f32(igt_handle* h, int32_t B, const float* x0, const float* u_prev,
+                        const float* kparams, const uint32_t* flags, const float* obs_xy,
+                        const float* tv_sv, const float* enc, float* x_out, float* u_out,
+                        float* cost_out, int32_t* argmin_out, int32_t* status_out, int mem,
+                        void* stream);
+int igt_solve_batch_f64(igt_handle* h, int32_t B, const double* x0, const double* u_prev,
+                        const double* kparams, const uint32_t* flags, const double* obs_xy,
+                        const double* tv_sv, const double* enc, double* x_out, double* u_out,
+                        double* cost_out, int32_t* argmin_out, int32_t* status_out, int mem,
+                        void* stream);
+
+/* Debug / parity entry: every candidate of every scenario.
+ *   X_all [B,C,7,N+1] (may be NULL)   U_all [B,C,2,N] (may be NULL)
+ *   cost_all [B,C]   viol_all [B,C] (IGT_VIOL_* bits; 0 = feasible) */
+int igt_rollout_batch_f32(igt_handle* h, int32_t B, const float* x0, const float* u_prev,
+                          const float* kparams, const uint32_t* flags, const float* obs_xy,
+                          const float* tv_sv, const float* enc, float* X_all, float* U_all,
+                          float* cost_all, uint32_t* viol_all, int mem, void* stream);
+int igt_rollout_batch_f64(igt_handle* h, int32_t B, const double* x0, const double* u_prev,
+                          const double* kparams, const uint32_t* flags, const double* obs_xy,
+                          const double* tv_sv, const double* enc, double* X_all, double* U_all,
+                          double* cost_all, uint32_t* viol_all, int mem, void* stream);
+
+/* 4-state Cartesian forward-Euler bicycle (kinematic_bicycle_model.py:15-50), the
+ * model ReferenceGen.py steps to lay out reference paths.
+ *   z0 [n,4] = (x, y, psi, v)   u [n,2,T] (a, df)   z_out [n,4,T+1] */
+int igt_cartesian_euler_f32(igt_handle* h, int32_t n, int32_t T, const float* z0, const float* u,
+                            float* z_out, int mem, void* stream);
+int igt_cartesian_euler_f64(igt_handle* h, int32_t n, int32_t T, const double* z0, const double* u,
+                            double* z_out, int mem, void* stream);
+
+/* Per-kernel timing with HIP events on the launch stream (used by bench.py for the
+ * roofline line).  While enabled, every solve records events around its kernels;
+ * igt_get_kernel_ms synchronises on them and returns the last call's durations. */
+int igt_set_profiling(igt_handle* h, int enable);
+int igt_get_kernel_ms(igt_handle* h, float* search_ms, float* emit_ms);
+
+/* Algorithmic HBM bytes one solve moves: reads + writes. */
+int igt_algorithmic_bytes_per_solve(const igt_handle* h, int elem_size, int64_t* read_bytes,
+                                    int64_t* write_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IGTMPC_H */

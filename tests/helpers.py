@@ -1,0 +1,48 @@
+"""Shared parity harness (tests only).  The oracle is the float64 numpy restatement in
+oracle/np_oracle.py, fed the SAME inputs as the device (float32 inputs are up-cast
+exactly), so differences are the kernel's arithmetic only."""
+import numpy as np
+
+import np_oracle as O
+
+REL_TOL = 1e-5       # BASELINE.json north_star: 1e-5 relative, |ref| floored at 1
+
+
+def rel_err(got, ref):
+    """|got-ref| / max(1,|ref|), elementwise."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+
+
+def oracle_params(solver):
+    p = solver.params
+    return O.Params(N=p.N, dt=p.dt, n_rk4=p.n_rk4, l_r=p.l_r, l_f=p.l_f, v_min=p.v_min, v_max=p.v_max,
+                    a_min=p.a_min, a_max=p.a_max, df_max=p.df_max, jerk=p.jerk_limit,
+                    steer_rate=p.steer_rate_limit, ey_lim=p.ey_lim, d_min=p.d_min, w_u=p.w_u,
+                    feas_tol=p.feas_tol)
+
+
+def oracle_solve(batch, P, C=256, cinf=None, U=None):
+    f = lambda k: np.asarray(batch[k], dtype=np.float64)
+    A, b = (None, None) if cinf is None else cinf
+    return O.solve_batch(f('x0'), f('u_prev'), f('kparams'), batch['flags'], f('obs_xy'), A, b, P, C=C, U=U,
+                         return_all=True)
+
+
+def ambiguous_mask(ref, P, eps_margin=2e-5, eps_cost=2e-5, eps_bp=2e-5, bp=None):
+    """Scenarios whose arg-min is decided inside float32 noise (documented in DESIGN.md):
+    some candidate that could win sits within eps of a constraint threshold, or the best
+    two feasible costs are closer than eps, or a stage argument of a contender lies
+    within eps of a curvature break-point."""
+    J, g, feas = ref['J'], ref['g'], ref['feas']
+    Jm = np.where(feas, J, np.inf)
+    best = Jm.min(axis=1)
+    contender = J <= (best[:, None] + eps_cost)             # could win if verdict flipped
+    near_thr = np.abs(g - P.feas_tol) < eps_margin
+    amb = (contender & near_thr).any(axis=1)
+    srt = np.sort(Jm, axis=1)
+    amb |= (srt[:, 1] - srt[:, 0]) < eps_cost
+    if bp is not None:
+        amb |= (contender & (bp < eps_bp)).any(axis=1)
+    return amb

@@ -1,0 +1,270 @@
+"""-m gpu : the HIP path (through the C ABI) against the float64 oracle.
+
+Bars:
+  f64 entry points : 1e-9 * max(1,|ref|)   (same operation order as the oracle; only libm differs)
+  f32 entry points : 1e-5 * max(1,|ref|)   (BASELINE.json north_star), arg-min / status exact
+                     on every scenario that is not decided inside float32 noise.
+"""
+import numpy as np
+import pytest
+
+import np_oracle as O
+from helpers import REL_TOL, ambiguous_mask, oracle_params, oracle_solve, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def igt():
+    import igtmpc
+    igtmpc.load_library()
+    return igtmpc
+
+
+def _batch(B, dtype, **kw):
+    from igtmpc.scenarios import make_batch
+    return make_batch(B, dtype=dtype, **kw)
+
+
+def _args(b):
+    return b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy']
+
+
+# ----------------------------------------------------------------------------- rollouts
+def test_rollout_all_f64_matches_oracle(igt):
+    b = _batch(96, np.float64)
+    with igt.BatchSolver(dtype='f64') as s:
+        P = oracle_params(s)
+        got = s.rollout_all(*_args(b))
+    ref = oracle_solve(b, P)
+    assert rel_err(got['U'], ref['U']).max() == 0.0
+    assert rel_err(got['X'], ref['X']).max() < 1e-9
+    fin = np.isfinite(ref['J'])
+    assert rel_err(got['cost'][fin], ref['J'][fin]).max() < 1e-9
+    clear = np.abs(ref['g'] - P.feas_tol) > 1e-9
+    assert ((got['viol'] == 0) == ref['feas'])[clear].all()
+    assert (got['viol'][clear] == ref['mask'][clear]).all()
+
+
+def test_rollout_all_f32_within_1e5(igt):
+    b = _batch(96, np.float32)
+    with igt.BatchSolver(dtype='f32') as s:
+        P = oracle_params(s)
+        got = s.rollout_all(*_args(b))
+    ref = oracle_solve(b, P)
+    # controls are generated in double on the device and only rounded on store
+    assert rel_err(got['U'], ref['U']).max() < 1e-7
+    kp = b['kparams'].astype(np.float64)[:, None, :]
+    x0 = O.apply_flags(b['x0'].astype(np.float64), b['flags'])[:, None, :]
+    bp = O.breakpoint_distance(x0, ref['U'], kp, P)
+    err = rel_err(got['X'], ref['X']).max(axis=(-1, -2))
+    clear = bp > 2e-5
+    assert clear.mean() > 0.98, 'too many break-point-sensitive rollouts in the sample'
+    assert err[clear].max() <= REL_TOL, f'max rel err {err[clear].max():.3e}'
+    # a curvature switch decided inside float32 noise moves a trajectory by O(1e-3) at most
+    assert err.max() < 5e-2
+    cerr = rel_err(got['cost'], ref['J'])
+    assert cerr[clear].max() <= REL_TOL
+    thr = np.abs(ref['g'] - P.feas_tol) > 2e-5
+    assert ((got['viol'] == 0) == ref['feas'])[clear & thr].all()
+
+
+# ----------------------------------------------------------------------------- solves
+@pytest.mark.parametrize('dtype,tol,eps', [('f64', 1e-9, 1e-9), ('f32', REL_TOL, 2e-5)])
+def test_solve_matches_oracle(igt, dtype, tol, eps):
+    npdt = np.float64 if dtype == 'f64' else np.float32
+    b = _batch(512, npdt)
+    with igt.BatchSolver(dtype=dtype) as s:
+        P = oracle_params(s)
+        got = s.solve(*_args(b))
+    ref = oracle_solve(b, P)
+    kp = b['kparams'].astype(np.float64)[:, None, :]
+    x0 = O.apply_flags(b['x0'].astype(np.float64), b['flags'])[:, None, :]
+    bp = O.breakpoint_distance(x0, ref['U'], kp, P)
+    amb = ambiguous_mask(ref, P, eps, eps, eps, bp)
+    assert amb.mean() < 0.10
+    ok = ~amb
+    assert (got['status'][ok] == ref['status'][ok]).all()
+    assert (got['argmin'][ok] == ref['argmin'][ok]).all()
+    sol = ok & (ref['status'] == 0)
+    assert sol.sum() > 50, 'sample has too few solvable scenarios to mean anything'
+    assert rel_err(got['x'][sol], ref['x'][sol]).max() <= tol
+    assert rel_err(got['u'][sol], ref['u'][sol]).max() <= max(tol, 1e-7)
+    assert rel_err(got['cost'][sol], ref['cost'][sol]).max() <= tol
+    # ambiguous scenarios: whatever was picked must still be a near-optimal, near-feasible candidate
+    for i in np.nonzero(amb)[0]:
+        c = got['argmin'][i]
+        if c >= 0:
+            best = np.where(ref['feas'][i], ref['J'][i], np.inf).min()
+            assert ref['g'][i, c] <= P.feas_tol + 10 * eps
+            assert ref['J'][i, c] <= best + 10 * eps or not np.isfinite(best)
+    # status-1 rows carry NaN / inf / -1
+    bad = got['status'] == 1
+    if bad.any():
+        assert np.isnan(got['x'][bad]).all() and np.isnan(got['u'][bad]).all()
+        assert np.isinf(got['cost'][bad]).all() and (got['argmin'][bad] == -1).all()
+
+
+def test_search_and_emit_agree_bitwise(igt):
+    """emit re-rolls the winner with the arithmetic search used: the trajectory it stores
+    must be exactly the rollout_all trajectory of that candidate."""
+    b = _batch(64, np.float32)
+    with igt.BatchSolver(dtype='f32') as s:
+        sol = s.solve(*_args(b))
+        allc = s.rollout_all(*_args(b))
+    for i in range(64):
+        c = sol['argmin'][i]
+        if c >= 0:
+            assert np.array_equal(sol['x'][i], allc['X'][i, c])
+            assert np.array_equal(sol['u'][i], allc['U'][i, c])
+            assert sol['cost'][i] == allc['cost'][i, c]
+            assert allc['viol'][i, c] == 0
+
+
+# ----------------------------------------------------------------------------- golden vectors
+def test_golden_frenet_rollouts_table_mode(igt, golden_dir):
+    """Reference-generated rollouts (tests/golden/frenet_rk4_golden.npz) through the table
+    candidate path: scenario i with table row i is the golden pair."""
+    g = np.load(f'{golden_dir}/frenet_rk4_golden.npz')
+    for dtype, npdt, tol in (('f64', np.float64, 1e-9), ('f32', np.float32, REL_TOL)):
+        worst = 0.0
+        with igt.BatchSolver(dtype=dtype, C=64, n_obs=0, cand_mode='table') as s:
+            P = oracle_params(s)
+            for lo in range(0, 1024, 64):
+                sl = slice(lo, lo + 64)
+                U = g['U'][sl]
+                s.set_candidate_table(U)
+                x0 = g['x0'][sl].astype(npdt)
+                kp = g['kp'][sl].astype(npdt)
+                out = s.rollout_all(x0, np.zeros((64, 2), npdt), kp, np.zeros(64, np.uint32),
+                                    np.zeros((64, 0, 2, 21), npdt))
+                got = out['X'][np.arange(64), np.arange(64)]
+                if dtype == 'f64':
+                    ref = g['X'][sl]
+                    bp = np.full(64, np.inf)
+                else:   # same (rounded) inputs through the oracle; golden pins the oracle itself
+                    ref = O.rollout_frenet(x0.astype(np.float64), U, kp.astype(np.float64), P)
+                    bp = O.breakpoint_distance(x0.astype(np.float64), U, kp.astype(np.float64), P)
+                e = rel_err(got, ref).max(axis=(-1, -2))
+                worst = max(worst, e[bp > 2e-5].max())
+        assert worst <= tol, f'{dtype}: {worst:.3e}'
+
+
+def test_survey_known_answer(igt):
+    """SURVEY.md section 4 KAT (reference model, recorded during the survey)."""
+    k = np.arange(20)
+    U = np.zeros((64, 2, 20))
+    U[0] = np.stack([0.5 * np.cos(0.3 * k), 0.1 * np.sin(0.2 * k)])
+    x0 = np.array([[18, 2.8, 18, 0.05, -0.02, 3, 0.0]])
+    kp = np.array([[19.3, 19.3 + 8.6 * np.pi / 2, 1 / 8.6]])
+    want20 = np.array([24.04054200868725, 3.1707601439799964, 23.768492505124048, -0.9596488518839958,
+                       -0.47896770505284986, 2.9547762875359105, 0.06025930720195858])
+    with igt.BatchSolver(dtype='f64', C=64, n_obs=0, cand_mode='table') as s:
+        s.set_candidate_table(U)
+        out = s.rollout_all(x0, np.zeros((1, 2)), kp, np.zeros(1, np.uint32), np.zeros((1, 0, 2, 21)))
+    assert rel_err(out['X'][0, 0, :, 20], want20).max() < 1e-12
+
+
+def test_golden_cartesian_euler(igt, golden_dir):
+    g = np.load(f'{golden_dir}/cartesian_euler_golden.npz')
+    with igt.BatchSolver(dtype='f64') as s:
+        z = s.cartesian_euler(g['z'], g['u'][:, :, None])
+    assert rel_err(z[:, :, 1], g['z_next']).max() < 1e-12
+    with igt.BatchSolver(dtype='f32') as s:
+        z = s.cartesian_euler(g['z'].astype(np.float32), g['u'][:, :, None].astype(np.float32))
+    assert rel_err(z[:, :, 1], g['z_next']).max() < REL_TOL
+
+
+# ----------------------------------------------------------------------------- edge cases
+def test_empty_and_ragged_batches(igt):
+    with igt.BatchSolver(dtype='f32') as s:
+        e = _batch(8, np.float32)
+        out = s.solve(*[a[:0] for a in _args(e)])
+        assert out['x'].shape == (0, 7, 21)
+        full = s.solve(*_args(e))
+        for B in (1, 3, 5, 7):       # not multiples of the 4 scenarios a workgroup holds
+            part = s.solve(*[a[:B] for a in _args(e)])
+            for k in ('x', 'u', 'cost', 'argmin', 'status'):
+                assert np.array_equal(part[k], full[k][:B], equal_nan=True)
+
+
+def test_all_infeasible_reports_status_1(igt):
+    b = _batch(16, np.float32)
+    b['x0'][:, 3] = 0.5      # |ey_0| > 0.2 -> every candidate violates mpc.py:296-299 at k = 0
+    with igt.BatchSolver(dtype='f32') as s:
+        out = s.solve(*_args(b))
+    assert (out['status'] == 1).all() and (out['argmin'] == -1).all()
+    assert np.isnan(out['x']).all() and np.isinf(out['cost']).all()
+
+
+@pytest.mark.parametrize('N,n_rk4,C,n_obs', [(10, 4, 256, 1), (40, 4, 64, 1), (20, 7, 64, 1), (20, 4, 1024, 1),
+                                             (20, 4, 256, 0), (20, 2, 256, 2)])
+def test_other_shapes_f64(igt, N, n_rk4, C, n_obs):
+    b = _batch(24, np.float64, N=N)
+    obs = np.concatenate([b['obs_xy']] * max(n_obs, 1), axis=1)[:, :n_obs]
+    if n_obs == 2:
+        obs[:, 1] += 3.0
+    with igt.BatchSolver(dtype='f64', N=N, n_rk4=n_rk4, C=C, n_obs=n_obs) as s:
+        P = oracle_params(s)
+        got = s.solve(b['x0'], b['u_prev'], b['kparams'], b['flags'], np.ascontiguousarray(obs))
+    bb = dict(b, obs_xy=obs)
+    ref = oracle_solve(bb, P, C=C)
+    amb = ambiguous_mask(ref, P, 1e-9, 1e-9)
+    ok = ~amb
+    assert (got['argmin'][ok] == ref['argmin'][ok]).all()
+    sol = ok & (ref['status'] == 0)
+    if sol.any():
+        assert rel_err(got['x'][sol], ref['x'][sol]).max() < 1e-9
+
+
+def test_bad_arguments_fail_loudly(igt):
+    with pytest.raises(igt.IgtError):
+        igt.BatchSolver(C=100)
+    with pytest.raises(igt.IgtError):
+        igt.BatchSolver(N=0)
+    with pytest.raises(igt.IgtError):
+        igt.BatchSolver(C=576)          # 24 x 24 lattice does not tile 64 lanes
+    with igt.BatchSolver(cand_mode='table') as s:
+        b = _batch(4, np.float32)
+        with pytest.raises(igt.IgtError):
+            s.solve(*_args(b))          # table never set
+
+
+# ----------------------------------------------------------------------------- full-size properties
+def test_full_size_properties(igt):
+    """BASELINE config 2 size (B=4096, C=256, N=20): size-independent properties."""
+    import torch
+    B = 4096
+    b = _batch(B, np.float32)
+    with igt.BatchSolver(dtype='f32') as s:
+        base = s.solve(*_args(b))
+        # (1) batch-permutation invariance
+        perm = np.random.default_rng(0).permutation(B)
+        p = s.solve(*[np.ascontiguousarray(a[perm]) for a in _args(b)])
+        for k in ('x', 'u', 'cost', 'argmin', 'status'):
+            assert np.array_equal(p[k], base[k][perm], equal_nan=True)
+        # (2) shard concatenation == unsharded (the multi-GPU partition, 8 logical shards)
+        parts = [s.solve(*[np.ascontiguousarray(a[i * 512:(i + 1) * 512]) for a in _args(b)]) for i in range(8)]
+        for k in ('x', 'u', 'cost', 'argmin', 'status'):
+            assert np.array_equal(np.concatenate([q[k] for q in parts]), base[k], equal_nan=True)
+        # (3) device-resident buffers (torch tensors, current stream) == host staging
+        dev = [torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda() for a in _args(b)]
+        d = s.solve(*dev)
+        torch.cuda.synchronize()
+        for k in ('x', 'u', 'cost', 'argmin', 'status'):
+            assert np.array_equal(d[k].cpu().numpy(), base[k], equal_nan=True)
+        # (4) the winner is feasible and optimal among ALL candidates per the device's own table
+        allc = s.rollout_all(*[a[:256] for a in _args(b)], want_X=False, want_U=False)
+        J = np.where(allc['viol'] == 0, allc['cost'], np.inf)
+        arg = J.argmin(axis=1)
+        okk = np.isfinite(J.min(axis=1))
+        assert (base['argmin'][:256][okk] == arg[okk]).all()
+        assert (base['status'][:256] == np.where(okk, 0, 1)).all()
+        # (5) trajectory is a rollout of its own controls (oracle, float64) on a sample
+        P = oracle_params(s)
+    idx = np.nonzero(base['status'] == 0)[0][:128]
+    x0 = O.apply_flags(b['x0'][idx].astype(np.float64), b['flags'][idx])
+    X = O.rollout_frenet(x0, base['u'][idx].astype(np.float64), b['kparams'][idx].astype(np.float64), P)
+    bp = O.breakpoint_distance(x0, base['u'][idx].astype(np.float64), b['kparams'][idx].astype(np.float64), P)
+    e = rel_err(base['x'][idx], X).max(axis=(-1, -2))
+    assert e[bp > 2e-5].max() <= REL_TOL

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Developer probe (GPU box): kernel times of the search/emit pair for a few configurations."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'igt-mpc-int_amd'))
+import torch  # noqa: E402
+
+from igtmpc import BatchSolver  # noqa: E402
+from igtmpc.scenarios import make_batch  # noqa: E402
+
+
+def run(dtype, B, nc, iters=5):
+    os.environ['IGT_NC'] = str(nc)
+    npdt = np.float32 if dtype == 'f32' else np.float64
+    b = make_batch(B, dtype=npdt)
+    args = [torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda()
+            for a in (b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy'])]
+    with BatchSolver(dtype=dtype) as s:
+        s.set_profiling(True)
+        out = s.solve(*args)
+        torch.cuda.synchronize()
+        ts, te, wall = [], [], []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            s.solve(*args, out=out)
+            torch.cuda.synchronize()
+            wall.append(time.perf_counter() - t0)
+            a, e = s.kernel_ms()
+            ts.append(a)
+            te.append(e)
+        st = out['status'].cpu().numpy()
+    ms, me, mw = np.median(ts), np.median(te), np.median(wall) * 1e3
+    print(f'{dtype} B={B:6d} NC={nc}: search {ms:8.3f} ms  emit {me:7.3f} ms  wall {mw:8.3f} ms  '
+          f'-> {B / (ms + me) * 1e3 / 1e6:7.3f} M solves/s (kernels)  feasible {np.mean(st == 0):.2f}', flush=True)
+
+
+if __name__ == '__main__':
+    for nc in (1, 2, 4):
+        run('f32', 4096, nc)
+    for nc in (1, 2, 4):
+        run('f32', 65536, nc)
+    run('f64', 4096, 1, iters=2)
