@@ -30,13 +30,20 @@ def _args(b):
     return b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy']
 
 
+def _cinf():
+    from igtmpc.cinf import cinf_halfplanes
+    return cinf_halfplanes()
+
+
 # ----------------------------------------------------------------------------- rollouts
 def test_rollout_all_f64_matches_oracle(igt):
     b = _batch(96, np.float64)
     with igt.BatchSolver(dtype='f64') as s:
         P = oracle_params(s)
+        s.set_cinf(*_cinf())
         got = s.rollout_all(*_args(b))
-    ref = oracle_solve(b, P)
+    ref = oracle_solve(b, P, cinf=_cinf())
+    assert (ref['mask'] & 16).any(), 'sample never exercises the terminal set'
     assert rel_err(got['U'], ref['U']).max() == 0.0
     assert rel_err(got['X'], ref['X']).max() < 1e-9
     fin = np.isfinite(ref['J'])
@@ -50,8 +57,9 @@ def test_rollout_all_f32_within_1e5(igt):
     b = _batch(96, np.float32)
     with igt.BatchSolver(dtype='f32') as s:
         P = oracle_params(s)
+        s.set_cinf(*_cinf())
         got = s.rollout_all(*_args(b))
-    ref = oracle_solve(b, P)
+    ref = oracle_solve(b, P, cinf=_cinf())
     # controls are generated in double on the device and only rounded on store
     assert rel_err(got['U'], ref['U']).max() < 1e-7
     kp = b['kparams'].astype(np.float64)[:, None, :]
@@ -76,8 +84,9 @@ def test_solve_matches_oracle(igt, dtype, tol, eps):
     b = _batch(512, npdt)
     with igt.BatchSolver(dtype=dtype) as s:
         P = oracle_params(s)
+        s.set_cinf(*_cinf())
         got = s.solve(*_args(b))
-    ref = oracle_solve(b, P)
+    ref = oracle_solve(b, P, cinf=_cinf())
     kp = b['kparams'].astype(np.float64)[:, None, :]
     x0 = O.apply_flags(b['x0'].astype(np.float64), b['flags'])[:, None, :]
     bp = O.breakpoint_distance(x0, ref['U'], kp, P)
@@ -237,6 +246,7 @@ def test_full_size_properties(igt):
     B = 4096
     b = _batch(B, np.float32)
     with igt.BatchSolver(dtype='f32') as s:
+        s.set_cinf(*_cinf())
         base = s.solve(*_args(b))
         # (1) batch-permutation invariance
         perm = np.random.default_rng(0).permutation(B)

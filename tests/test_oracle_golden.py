@@ -1,0 +1,106 @@
+"""CPU: the oracle (numpy + C restatements) against the reference-generated golden vectors
+(tests/golden/*.npz, made by tests/golden/make_golden.py) and the SURVEY section 4 KAT."""
+import json
+
+import numpy as np
+import pytest
+
+import np_oracle as O
+
+
+def test_frenet_rollout_bit_exact(golden_dir):
+    g = np.load(f'{golden_dir}/frenet_rk4_golden.npz')
+    X = O.rollout_frenet(g['x0'], g['U'], g['kp'], O.Params(n_rk4=int(g['n_rk4']), dt=float(g['dt'])))
+    assert np.array_equal(X, g['X'])          # 1024 rollouts x 20 steps, 0 ulp
+
+
+def test_frenet_rollout_rk7_bit_exact(golden_dir):
+    g = np.load(f'{golden_dir}/frenet_rk4_golden_rk7.npz')
+    X = O.rollout_frenet(g['x0'], g['U'], g['kp'], O.Params(n_rk4=7))
+    assert np.array_equal(X, g['X'])
+
+
+def test_cartesian_euler_bit_exact(golden_dir):
+    g = np.load(f'{golden_dir}/cartesian_euler_golden.npz')
+    z = O.cartesian_euler_step(g['z'], g['u'][:, 0], g['u'][:, 1], O.Params())
+    assert np.array_equal(z, g['z_next'])
+
+
+def test_survey_known_answer_vectors():
+    """SURVEY.md section 4 table (recorded from the reference during the survey)."""
+    k = np.arange(20)
+    U = np.stack([0.5 * np.cos(0.3 * k), 0.1 * np.sin(0.2 * k)])
+    x0 = np.array([18, 2.8, 18, 0.05, -0.02, 3, 0.0])
+    kp = np.array([19.3, 19.3 + 8.6 * np.pi / 2, 1 / 8.6])
+    X = O.rollout_frenet(x0, U, kp, O.Params())
+    want = {1: [18.302499999999995, 2.8, 18.30243950201664, 0.04395040332526674, -0.02, 3.0500000000000007, 0.0],
+            10: [21.127355623760682, 2.956599698035115, 21.132911009599095, -0.05072384947021227,
+                 -0.18613145838029138, 3.0730931485799537, 0.046632589278592346],
+            20: [24.04054200868725, 3.1707601439799964, 23.768492505124048, -0.9596488518839958,
+                 -0.47896770505284986, 2.9547762875359105, 0.06025930720195858]}
+    for kk, w in want.items():
+        assert np.array_equal(X[:, kk], np.array(w))
+    z = O.cartesian_euler_step(np.array([1.0, 2.8, 0.1, 5.0]), 0.3, 0.05, O.Params())
+    assert np.array_equal(z, np.array([1.496097858923633, 2.8623451230762056, 0.10559575521166592, 5.03]))
+
+
+def test_value_net_forward_matches_reference(golden_dir):
+    v = np.load(f'{golden_dir}/value_net_golden.npz')
+    for sc in (1, 3):
+        layers, i = [], 0
+        while f'sc{sc}_W{i}' in v:
+            layers.append((v[f'sc{sc}_W{i}'], v[f'sc{sc}_b{i}']))
+            i += 1
+        assert len(layers) == (3 if sc == 1 else 4)
+        out = O.value_net_forward(layers, v['z'])[:, 0]
+        assert np.abs(out - v[f'V_sc{sc}']).max() < 1e-13
+
+
+def test_c_restatement_matches_numpy():
+    import c_oracle as CO
+    from igtmpc.cinf import cinf_halfplanes
+    from igtmpc.scenarios import make_batch
+    A, b = cinf_halfplanes()
+    bt = make_batch(48, dtype=np.float64)
+    P = O.Params()
+    a = (bt['x0'], bt['u_prev'], bt['kparams'], bt['flags'], bt['obs_xy'], A, b, P)
+    ref = O.solve_batch(*a, return_all=True)
+    allc = CO.rollout_all(*a, nthreads=4)
+    assert np.array_equal(allc['U'], ref['U'])
+    assert np.abs(allc['X'] - ref['X']).max() < 1e-12
+    assert np.array_equal(allc['viol'], ref['mask'].astype(np.uint32))
+    got = CO.solve_batch(*a, nthreads=4)
+    assert np.array_equal(got['argmin'], ref['argmin']) and np.array_equal(got['status'], ref['status'])
+    ok = ref['status'] == 0
+    assert ok.any() and (~ok).any()
+    assert np.abs(got['x'][ok] - ref['x'][ok]).max() < 1e-12
+    assert np.isnan(got['x'][~ok]).all() and np.isinf(got['cost'][~ok]).all()
+
+
+def test_c_restatement_on_golden(golden_dir):
+    import c_oracle as CO
+    g = np.load(f'{golden_dir}/frenet_rk4_golden.npz')
+    P = O.Params()
+    sl = slice(0, 64)
+    out = CO.rollout_all(g['x0'][sl], np.zeros((64, 2)), g['kp'][sl], np.zeros(64, np.uint32), None, None, None, P,
+                         C=64, U=g['U'][sl])
+    got = out['X'][np.arange(64), np.arange(64)]
+    assert np.abs(got - g['X'][sl]).max() < 1e-12
+
+
+def test_oracle_solve_edge_cases():
+    from igtmpc.scenarios import make_batch
+    P = O.Params()
+    bt = make_batch(8, dtype=np.float64)
+    bt['x0'][:, 3] = 0.5                                   # every candidate violates |ey| <= 0.2 at k = 0
+    r = O.solve_batch(bt['x0'], bt['u_prev'], bt['kparams'], bt['flags'], bt['obs_xy'], None, None, P)
+    assert (r['status'] == 1).all() and (r['argmin'] == -1).all() and np.isnan(r['x']).all()
+    # tie-break: with identical candidates (table of copies) the lowest index wins
+    bt = make_batch(4, dtype=np.float64)
+    U = np.zeros((64, 2, 20))
+    r = O.solve_batch(bt['x0'], np.zeros((4, 2)), bt['kparams'], bt['flags'], None, None, None, P, C=64, U=U,
+                      return_all=True)
+    assert ((r['argmin'] == 0) | (r['status'] == 1)).all()
+    # abs-heading flag (mpc.py:231-234)
+    x = O.apply_flags(np.array([[0, 0, 0, 0, 0, 1, -3.0]]), np.array([1], dtype=np.uint32))
+    assert x[0, 6] == 3.0
