@@ -231,6 +231,37 @@ int rollout_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T
 }
 
 template <typename T>
+int frenet_step_impl(igt_handle* h, int32_t n, const T* x, const T* u, const T* kparams, T* x_next, int mem,
+                     void* stream) {
+    if (!h) return fail(IGT_E_INVALID, "null handle");
+    if (n < 0) return fail(IGT_E_INVALID, "negative size");
+    if (n == 0) return IGT_OK;
+    if (!x || !u || !kparams || !x_next) return fail(IGT_E_INVALID, "null buffer");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const size_t n_x = (size_t)n * 7, n_u = (size_t)n * 2, n_k = (size_t)n * 3;
+    const T *dx = x, *du = u, *dk = kparams;
+    T* dout = x_next;
+    if (mem == IGT_MEM_HOST) {
+        if (int rc = ensure_stage(h, (2 * n_x + n_u + n_k) * sizeof(T) + 8 * 256)) return rc;
+        Arena ar{(char*)h->d_stage, 0};
+        T* a = ar.take<T>(n_x); T* b = ar.take<T>(n_u); T* c = ar.take<T>(n_k); dout = ar.take<T>(n_x);
+        HIPCHK(hipMemcpyAsync(a, x, n_x * sizeof(T), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(b, u, n_u * sizeof(T), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(c, kparams, n_k * sizeof(T), hipMemcpyHostToDevice, st));
+        dx = a; du = b; dk = c;
+    } else if (mem != IGT_MEM_DEVICE) {
+        return fail(IGT_E_INVALID, "mem must be IGT_MEM_DEVICE or IGT_MEM_HOST");
+    }
+    HIPCHK(igt::launch_frenet_step<T>(h->kp, n, dx, du, dk, dout, st));
+    if (mem == IGT_MEM_HOST) {
+        HIPCHK(hipMemcpyAsync(x_next, dout, n_x * sizeof(T), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return IGT_OK;
+}
+
+template <typename T>
 int cartesian_impl(igt_handle* h, int32_t n, int32_t steps, const T* z0, const T* u, T* z_out, int mem, void* stream) {
     if (!h) return fail(IGT_E_INVALID, "null handle");
     if (n < 0 || steps < 0) return fail(IGT_E_INVALID, "negative size");
@@ -399,6 +430,15 @@ int igt_rollout_batch_f64(igt_handle* h, int32_t B, const double* x0, const doub
                           double* X_all, double* U_all, double* cost_all, uint32_t* viol_all, int mem, void* stream) {
     (void)tv_sv; (void)enc;
     return rollout_impl<double>(h, B, x0, u_prev, kparams, flags, obs_xy, X_all, U_all, cost_all, viol_all, mem, stream);
+}
+
+int igt_frenet_step_f32(igt_handle* h, int32_t n, const float* x, const float* u, const float* kparams, float* x_next,
+                        int mem, void* stream) {
+    return frenet_step_impl<float>(h, n, x, u, kparams, x_next, mem, stream);
+}
+int igt_frenet_step_f64(igt_handle* h, int32_t n, const double* x, const double* u, const double* kparams,
+                        double* x_next, int mem, void* stream) {
+    return frenet_step_impl<double>(h, n, x, u, kparams, x_next, mem, stream);
 }
 
 int igt_cartesian_euler_f32(igt_handle* h, int32_t n, int32_t T, const float* z0, const float* u, float* z_out,

@@ -155,6 +155,29 @@ __global__ __launch_bounds__(256) void rollout_all_kernel(KP P, int B, const T* 
     }
 }
 
+// one control step for n independent states (kinematic_bicycle_model_frenet.py:70-127)
+template <class Stepper, typename T>
+__global__ __launch_bounds__(256) void frenet_step_kernel(KP P, int n, const T* __restrict__ x,
+                                                          const T* __restrict__ u, const T* __restrict__ kparams,
+                                                          T* __restrict__ x_next) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double x0[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) x0[k] = (double)x[(size_t)i * 7 + k];
+    Stepper stp;
+    stp.init(P, (double)kparams[(size_t)i * 3 + 0], (double)kparams[(size_t)i * 3 + 1],
+             (double)kparams[(size_t)i * 3 + 2]);
+    typename Stepper::State st;
+    stp.set(st, x0);
+    const double a = (double)u[(size_t)i * 2 + 0], df = (double)u[(size_t)i * 2 + 1];
+    stp.step(st, a, stp.prep(df));
+    double o[7];
+    stp.get(st, o);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) x_next[(size_t)i * 7 + k] = (T)o[k];
+}
+
 // kinematic_bicycle_model.py:27-31, T steps per trajectory
 template <typename T>
 __global__ __launch_bounds__(256) void cartesian_euler_kernel(int n, int steps, T dt, T l_r, T l_f,
@@ -237,6 +260,21 @@ hipError_t launch_rollout_all<double>(const KP& P, int B, const SolveArgs<double
                                       double* cost_all, uint32_t* viol_all, hipStream_t st) {
     hipLaunchKernelGGL((rollout_all_kernel<ExactStepper<double>, double>), dim3((B + 3) / 4), dim3(256), 0, st, P, B,
                        A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, X_all, U_all, cost_all, viol_all);
+    return hipGetLastError();
+}
+
+template <>
+hipError_t launch_frenet_step<float>(const KP& P, int n, const float* x, const float* u, const float* kparams,
+                                     float* x_next, hipStream_t st) {
+    hipLaunchKernelGGL((frenet_step_kernel<FastStepper, float>), dim3((n + 255) / 256), dim3(256), 0, st, P, n, x, u,
+                       kparams, x_next);
+    return hipGetLastError();
+}
+template <>
+hipError_t launch_frenet_step<double>(const KP& P, int n, const double* x, const double* u, const double* kparams,
+                                      double* x_next, hipStream_t st) {
+    hipLaunchKernelGGL((frenet_step_kernel<ExactStepper<double>, double>), dim3((n + 255) / 256), dim3(256), 0, st, P,
+                       n, x, u, kparams, x_next);
     return hipGetLastError();
 }
 

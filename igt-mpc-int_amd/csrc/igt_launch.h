@@ -30,6 +30,8 @@ template <typename T>
 hipError_t launch_rollout_all(const KP& P, int B, const SolveArgs<T>& A, T* X_all, T* U_all, T* cost_all,
                               uint32_t* viol_all, hipStream_t st);
 template <typename T>
+hipError_t launch_frenet_step(const KP& P, int n, const T* x, const T* u, const T* kparams, T* x_next, hipStream_t st);
+template <typename T>
 hipError_t launch_cartesian(int n, int steps, double dt, double l_r, double l_f, const T* z0, const T* u, T* z_out,
                             hipStream_t st);
 

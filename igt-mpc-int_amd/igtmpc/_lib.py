@@ -29,6 +29,7 @@ _vp, _i32, _i = C.c_void_p, C.c_int32, C.c_int
 _SOLVE = [_vp, _i32] + [_vp] * 12 + [_i, _vp]
 _ROLL = [_vp, _i32] + [_vp] * 11 + [_i, _vp]
 _CART = [_vp, _i32, _i32, _vp, _vp, _vp, _i, _vp]
+_FSTEP = [_vp, _i32, _vp, _vp, _vp, _vp, _i, _vp]
 SYMBOLS = {
     'igt_version': (_i, []),
     'igt_last_error': (C.c_char_p, []),
@@ -43,6 +44,8 @@ SYMBOLS = {
     'igt_solve_batch_f64': (_i, _SOLVE),
     'igt_rollout_batch_f32': (_i, _ROLL),
     'igt_rollout_batch_f64': (_i, _ROLL),
+    'igt_frenet_step_f32': (_i, _FSTEP),
+    'igt_frenet_step_f64': (_i, _FSTEP),
     'igt_cartesian_euler_f32': (_i, _CART),
     'igt_cartesian_euler_f64': (_i, _CART),
     'igt_set_profiling': (_i, [_vp, _i]),

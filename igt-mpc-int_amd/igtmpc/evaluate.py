@@ -1,0 +1,156 @@
+"""Closed-loop driver: the time loop of the reference's evaluate.py (mpc branch 451-564, gt_mpc
+branch 193-330) for E episodes in lock-step, every (episode, agent) problem of a timestep solved
+in ONE batched call on the GPU (the reference's agents of a timestep all read the same
+predictions -- a Jacobi update, evaluate.py:469-558 -- so batching changes nothing).
+
+Kept from the reference, with citations:
+  * initial states: random offset along the approach lane, v0 = 0, s = offset      (evaluate.py:91-94, 404-418)
+  * previous inputs start at (0.1, 0)                                               (evaluate.py:419)
+  * per step: predict -> share motion forecasts (V2V) -> filter_preds -> solve      (evaluate.py:455-482)
+  * solved: next state = x*[:,1], applied input = u*[:,0]                           (evaluate.py:491-510)
+  * infeasible: brake a = a_min (if v > 0 else 0), keep df, one model step; v < 0 -> stop  (evaluate.py:511-545)
+  * deadlock: at least two agents end with s <= 30                                  (evaluate.py:566-569)
+Not kept: pickles / CSV / mp4 output, the unseeded route shuffle (routes are sorted pairs here).
+
+    python -m igtmpc.evaluate --sc 1 --num_samples 8 --N 20
+"""
+import argparse
+import json
+import time
+
+import numpy as np
+
+from . import routes as R
+from .cinf import cinf_halfplanes
+from .predictor import ConstantAccelerationModel
+from .solver import BatchSolver
+
+A_MIN_POLICY = -4.0        # mpc.yaml:8, used by the brake fallback (evaluate.py:514)
+
+
+def initial_states(rng, route_pairs):
+    """evaluate.py:91-94 + 404-418: every episode draws one offset per approach lane (order 1,2,3,4);
+    an agent starting at origin o sits `offset_o` metres down its lane with v = 0, ey = epsi = 0."""
+    E = len(route_pairs)
+    max_start = (R.ROAD_LENGTH - R.ROAD_WIDTH) / 2 - (R.ROAD_WIDTH - R.CA_RADIUS)      # evaluate.py:48-49
+    off = rng.random((E, 4)) * max_start
+    M = 2
+    x = np.zeros((E, M, 7))
+    rid = np.zeros((E, M), dtype=np.int64)
+    for e, pair in enumerate(route_pairs):
+        for m, r in enumerate(pair):
+            rid[e, m] = R.ROUTE_ID[r]
+            s0 = off[e, int(r[0]) - 1]
+            xy = R.frenet2global(rid[e, m], s0)
+            h0 = {'1': 0.0, '2': -np.pi / 2, '3': -np.pi, '4': np.pi / 2}[r[0]]     # evaluate.py:58-61
+            x[e, m] = (xy[0], xy[1], s0, 0.0, 0.0, 0.0, h0)
+    return x, rid
+
+
+def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=256, n_rk4=4, device=0,
+                    dtype='f32', rotation=None, cand_mode='lattice', verbose=False):
+    rng = np.random.default_rng(seed)                                   # evaluate.py:35, 56
+    E, M = num_samples, 2
+    M_sim = int(T_sim / dt)                                             # evaluate.py:83-84
+    pairs = [R.SCENARIO_ROUTES[sc - 1][(e if rotation is None else rotation) % 4] for e in range(E)]
+    x, rid = initial_states(rng, pairs)                                 # x[E,M,7]
+    kp = R.kparams(rid)                                                 # [E,M,3]
+    absh = R.TABLES['abs_heading'][rid]
+    flags = absh.astype(np.uint32).reshape(-1)
+    u_prev = np.tile(np.array([0.1, 0.0]), (E, M, 1))                   # evaluate.py:419
+    predictor = ConstantAccelerationModel(N=N, dt=dt)                   # evaluate.py:76-77
+    solver = BatchSolver(N=N, dt=dt, n_rk4=n_rk4, C=C, n_obs=M - 1, device=device, dtype=dtype, cand_mode=cand_mode)
+    solver.set_cinf(*cinf_halfplanes(dt=dt, jerk=solver.params.jerk_limit))
+    stepper = BatchSolver(N=1, dt=dt, n_rk4=n_rk4, C=64, n_obs=0, device=device, dtype='f64')
+    npdt = solver.np_dtype
+
+    x_data = np.zeros((E, 7 * M, M_sim + 1))
+    u_data = np.zeros((E, 2 * M, M_sim))
+    x_data[:, :, 0] = x.reshape(E, 7 * M)
+    infeasible = np.zeros((E, M), dtype=np.int64)
+    solve_ms = []
+    have_sol = np.zeros((E, M), dtype=bool)
+    sol_x = np.zeros((E, M, 7, N + 1))
+    sol_u = np.zeros((E, M, 2, N))
+
+    for t in range(M_sim):
+        # --- predict (evaluate.py:455): constant acceleration with the previously applied a
+        pr = predictor.predict_arrays(x[..., 2].reshape(-1), x[..., 5].reshape(-1), u_prev[..., 0].reshape(-1),
+                                      rid.reshape(-1))
+        px = pr['x'].reshape(E, M, N + 1).copy()
+        py = pr['y'].reshape(E, M, N + 1).copy()
+        px[:, :, 0], py[:, :, 0] = x[..., 0], x[..., 1]                 # k = 0 is the true state (cam:40)
+        # --- V2V: agents that solved last step share their plan (utils.py:339-352)
+        if t > 0 and have_sol.any():
+            last = sol_x[:, :, :, N]                                    # last state of the shared plan
+            a_last = sol_u[:, :, 0, N - 1]
+            ext = predictor.predict_arrays(last[..., 2].reshape(-1), last[..., 5].reshape(-1), a_last.reshape(-1),
+                                           rid.reshape(-1))
+            redo = ext['v'][:, 1] > 5                                   # utils.py:348-349: retry with a = 0
+            if redo.any():
+                ext0 = predictor.predict_arrays(last[..., 2].reshape(-1), last[..., 5].reshape(-1),
+                                                np.where(redo, 0.0, a_last.reshape(-1)), rid.reshape(-1))
+                for k in ('x', 'y'):
+                    ext[k] = np.where(redo[:, None], ext0[k], ext[k])
+            sx = np.concatenate([sol_x[:, :, 0, 1:], ext['x'][:, 1].reshape(E, M, 1)], axis=2)
+            sy = np.concatenate([sol_x[:, :, 1, 1:], ext['y'][:, 1].reshape(E, M, 1)], axis=2)
+            px = np.where(have_sol[..., None], sx, px)
+            py = np.where(have_sol[..., None], sy, py)
+        # --- per ego: the other agent's forecast, filtered (utils.py:365-388)
+        obs = np.stack([px[:, ::-1], py[:, ::-1]], axis=2).reshape(E * M, 1, 2, N + 1)
+        ego_xy = np.stack([px[:, :, 0], py[:, :, 0]], axis=-1).reshape(E * M, 2)
+        obs = R.filter_preds(ego_xy, x[..., 6].reshape(-1), obs)
+        # --- solve every (episode, agent) problem at once (evaluate.py:470-482)
+        t0 = time.perf_counter()
+        out = solver.solve(x.reshape(E * M, 7).astype(npdt), u_prev.reshape(E * M, 2).astype(npdt),
+                           kp.reshape(E * M, 3).astype(npdt), flags, obs.astype(npdt))
+        solve_ms.append((time.perf_counter() - t0) * 1e3)
+        ok = (out['status'] == 0).reshape(E, M)
+        xs = out['x'].reshape(E, M, 7, N + 1).astype(np.float64)
+        us = out['u'].reshape(E, M, 2, N).astype(np.float64)
+        # --- infeasible: brake fallback (evaluate.py:511-545)
+        v_now = x[..., 5]
+        a_fb = np.where(v_now > 0, A_MIN_POLICY, 0.0)
+        u_fb = np.stack([a_fb, u_prev[..., 1]], axis=-1)
+        nxt_fb = stepper.frenet_step(x.reshape(E * M, 7), u_fb.reshape(E * M, 2), kp.reshape(E * M, 3)).reshape(E, M, 7)
+        neg = v_now < 0                                                 # evaluate.py:523-526: instantaneous stop
+        stop = x.copy()
+        stop[..., 5] = 0.0
+        nxt_fb = np.where(neg[..., None], stop, nxt_fb)
+        u_fb[..., 0] = np.where(neg, 0.0, u_fb[..., 0])
+        x_next = np.where(ok[..., None], xs[:, :, :, 1], nxt_fb)
+        u_app = np.where(ok[..., None], us[:, :, :, 0], u_fb)
+        infeasible += ~ok
+        x, u_prev = x_next, u_app
+        have_sol, sol_x, sol_u = ok, np.nan_to_num(xs), np.nan_to_num(us)
+        x_data[:, :, t + 1] = x.reshape(E, 7 * M)
+        u_data[:, :, t] = u_app.reshape(E, 2 * M)
+        if verbose and t % 10 == 0:
+            print(f't={t:3d} s={x[0, :, 2].round(2)} v={x[0, :, 5].round(2)} ok={ok[0]}', flush=True)
+
+    deadlock = (x_data[:, 2::7, -1] <= 30).sum(axis=1) >= 2             # evaluate.py:566-569
+    solver.close()
+    stepper.close()
+    return dict(x_data=x_data, u_data=u_data, infeasible_ratio=infeasible / M_sim, deadlock=deadlock,
+                routes=pairs, solve_ms=np.array(solve_ms))
+
+
+def main():
+    ap = argparse.ArgumentParser(description='batched closed-loop evaluation (counterpart of evaluate.py --eval_mode mpc)')
+    ap.add_argument('--sc', type=int, default=1)
+    ap.add_argument('--num_samples', type=int, default=1)
+    ap.add_argument('--N', type=int, default=20)
+    ap.add_argument('--C', type=int, default=256)
+    ap.add_argument('--eval_mode', default='mpc', choices=['mpc'])
+    ap.add_argument('--verbose', action='store_true')
+    a = ap.parse_args()
+    r = run_closed_loop(sc=a.sc, num_samples=a.num_samples, N=a.N, C=a.C, verbose=a.verbose)
+    print(json.dumps({'sc': a.sc, 'episodes': a.num_samples, 'routes': r['routes'][:4],
+                      'infeasible_ratio_mean': r['infeasible_ratio'].mean(axis=0).tolist(),
+                      'deadlock_rate': float(r['deadlock'].mean()),
+                      'final_s_mean': r['x_data'][:, 2::7, -1].mean(axis=0).tolist(),
+                      'avg_solve_ms_per_step': float(r['solve_ms'][5:].mean())}))
+
+
+if __name__ == '__main__':
+    main()

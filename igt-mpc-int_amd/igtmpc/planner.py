@@ -1,0 +1,149 @@
+"""MPC_Planner -- same constructor keywords, methods and return contract as the reference
+planner (mpc.py:19-406), so an evaluate.py-style driver can swap it in.
+
+What changes underneath: no CasADi NLP is built and no IPOPT runs.  `solve` hands the current
+initial condition and predictions to the batched shooting solver in libigtmpc.so (one wavefront
+per (scenario, ego) problem on the MI355X) and returns the feasible arg-min of the candidate set.
+Planners created with the same discretisation share one solver handle per device; the batched
+entry (`BatchSolver.solve`) is the throughput path, this class is the per-agent compatibility face.
+"""
+import time
+
+import numpy as np
+
+from .cinf import cinf_halfplanes
+from .solver import BatchSolver
+from .vehicle import Curvature, VehicleAction, VehicleReference  # noqa: F401  (re-exported for drivers)
+
+_SHARED = {}
+
+
+class _Stats:
+    """Stand-in for casadi's OptiSol as far as evaluate.py reads it (evaluate.py:294-295, 549-552)."""
+
+    def __init__(self, t, status, cost, argmin):
+        self._d = {'t_wall_total': t, 'success': status == 0, 'return_status': 'Solve_Succeeded' if status == 0 else
+                   'Infeasible_Problem_Detected', 'cost': cost, 'argmin': argmin}
+
+    def stats(self):
+        return dict(self._d)
+
+
+class MPC_Planner:
+    def __init__(self, N=10, dt=0.1, agents=None, goals=None, ca_radius=2.8, ref=None, road_dim=(10, 50),
+                 routes=None, ds_right=None, index=None, num_rk4_steps=7, solver='ipopt', ca_type='circle',
+                 nn_config_dir=None, use_NN_cost2go=False, weights=(1, 1, 1),
+                 C=256, device=0, dtype='f32', value_net=None):
+        assert agents is not None, 'Agents are not defined'           # mpc.py:155
+        assert index is not None                                      # mpc.py:80
+        if ca_type != 'circle':
+            # OBCA needs dual variables as decision variables (mpc.py:211-221): not a shooting constraint
+            raise NotImplementedError("only ca_type='circle' (mpc.yaml:16) is supported")
+        self.N, self.dt, self.ca_type = N, dt, ca_type
+        self.x_sol_prev = None
+        self.d_min = 2 * ca_radius                                    # mpc.py:45
+        self.l = 4.47; self.l_f = 4.47 / 2; self.l_r = 4.47 / 2; self.width = 2.0      # mpc.py:48-51
+        self.routes = routes
+        self.steering_rate_limit = 0.7; self.jerk_limit = 0.9         # mpc.py:55-56
+        self.v_min, self.v_max, self.a_min, self.a_max = 0, 5, -4, 3  # mpc.py:57-60
+        self.ey_lim, self.max_steering = 0.2, 1                       # mpc.py:61-62
+        self.use_NN_cost2go = use_NN_cost2go
+        self.road_width, self.road_length = road_dim                  # mpc.py:65-66
+        self.ref, self.ds_right, self.weights, self.goals = ref, ds_right, weights, goals
+        self.nx, self.nu = 7, 2
+        self.agents, self.ind = agents, index
+        self.initial_agent = agents[index]
+        self.M = len(ref) if ref is not None else len(agents)         # mpc.py:82
+        self.num_obstacles = self.M - 1
+        self.pred_ind = [i for i in range(self.M) if i != index]
+        self.NN_query_time = -1
+        self.solve_time = 0.0
+        self.sol = None
+        # curvature of the ego route (mpc.py:183-200)
+        route = routes[index]
+        if ref is not None and 'K' in ref[index]:
+            self.K = Curvature.from_reference(ref[index]['K'], route, road_dim, ds_right if ds_right is not None else
+                                              self.road_width - ca_radius)
+        else:
+            self.K = Curvature.from_route(route)
+        self._abs_heading = [r in ('32', '41') for r in routes]       # mpc.py:231, 250, 273, 282
+        # terminal set (mpc.py:88-104) -- same for every planner with this dt
+        self.C_inf = cinf_halfplanes(dt=dt, jerk=self.jerk_limit)
+        cost_mode = 'value_net' if use_NN_cost2go else 'progress'
+        key = (N, dt, num_rk4_steps, C, self.num_obstacles, device, dtype, cost_mode, self.d_min, id(value_net))
+        if key not in _SHARED:
+            s = BatchSolver(N=N, dt=dt, n_rk4=num_rk4_steps, C=C, n_obs=self.num_obstacles, device=device,
+                            dtype=dtype, cost_mode=cost_mode, d_min=self.d_min)
+            s.set_cinf(*self.C_inf)
+            if use_NN_cost2go:
+                if value_net is None:
+                    raise ValueError('use_NN_cost2go=True needs value_net=dict(layers, Wn, mu_f, sigma_t, mu_t): the '
+                                     "reference's normalisation statistics live in a dataset that is not shipped")
+                s.set_value_net(**value_net)
+            _SHARED[key] = s
+        self._solver = _SHARED[key]
+        self._dt = self._solver.np_dtype
+        self._x0 = np.zeros((1, 7), self._dt)
+        self._u_prev = np.zeros((1, 2), self._dt)
+        self._obs = np.zeros((1, self.num_obstacles, 2, N + 1), self._dt)
+        self._tv_sv = np.zeros((1, 2), self._dt)
+        self._enc = np.zeros((1, 2), self._dt)
+        if use_NN_cost2go:
+            from .routes import scenario_encoding_sign, scenario_of
+            e = scenario_encoding_sign(list(routes), scenario_of(list(routes)))      # mpc.py:336-337
+            j = self.pred_ind[0]
+            self._enc[0] = (e[index], e[j])
+        self.update_initial_condition(self.initial_agent, VehicleAction({'a': 0.0, 'df': 0.0}))
+
+    # ------------------------------------------------------------------ mpc.py:280-294
+    def update_initial_condition(self, agent, u_prev):
+        self.u_prev_raw = u_prev
+        st = agent['state']
+        self._x0[0] = (st.x, st.y, st.s, st.ey, st.epsi, st.v, st.heading)
+        self._u_prev[0] = (u_prev.a, u_prev.df)
+        self.initial_agent = agent
+
+    # ------------------------------------------------------------------ mpc.py:241-278
+    def update_predictions(self, preds, raw_preds=None):
+        assert len(preds) == self.M, ValueError('Invalid number of predictions')
+        m = 0
+        self.pred_ind = []
+        for i, pred in enumerate(preds):
+            if i != self.ind:
+                self.pred_ind.append(i)
+                assert len(pred) == self.N + 1, ValueError('Invalid prediction length (Horizon)')
+                # only x,y of the obstacle block are read by the cost / constraints (mpc.py:223-226)
+                self._obs[0, m, 0] = [p.x for p in pred]
+                self._obs[0, m, 1] = [p.y for p in pred]
+                m += 1
+        if raw_preds is not None:
+            self.raw_preds_np = np.zeros((1, self.nx * self.M))
+            for i, pred in enumerate(raw_preds):
+                p = pred[-1]
+                self.raw_preds_np[0, self.nx * i:self.nx * (i + 1)] = [p.x, p.y, p.s, p.ey, p.epsi, p.v, p.heading]
+            j = self.pred_ind[0]                                       # mpc.py:329-330
+            self._tv_sv[0] = (raw_preds[j][-1].s, raw_preds[j][-1].v)
+        self.NN_query_time = -1                                        # mpc.py:278
+
+    # ------------------------------------------------------------------ mpc.py:383-406
+    def solve(self, x_sol_prev=None, u_sol_prev=None):
+        """-> (x[7,N+1], u[2,N], True) or (None, None, False); never raises on an infeasible problem.
+        The warm start of the NLP has no counterpart in sampled shooting and is ignored."""
+        flags = np.array([1 if self._abs_heading[self.ind] else 0], dtype=np.uint32)
+        kp = np.array([self.K.kparams], dtype=self._dt)
+        t0 = time.time()
+        out = self._solver.solve(self._x0, self._u_prev, kp, flags, self._obs,
+                                 self._tv_sv if self.use_NN_cost2go else None,
+                                 self._enc if self.use_NN_cost2go else None)
+        self.solve_time = time.time() - t0
+        status = int(out['status'][0])
+        self.sol = _Stats(self.solve_time, status, float(out['cost'][0]), int(out['argmin'][0]))
+        if status != 0:
+            return (None, None, False)
+        x = np.array(out['x'][0], dtype=np.float64)
+        u = np.array(out['u'][0], dtype=np.float64)
+        self.x_sol_prev = x
+        return (x, u, True)
+
+    def cost_function(self):
+        raise NotImplementedError('the cost is evaluated inside the kernels (csrc/igt_device.h); see CAV_utility there')

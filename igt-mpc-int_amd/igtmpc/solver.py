@@ -47,6 +47,7 @@ class BatchSolver:
         self._solve = getattr(self.lib, f'igt_solve_batch_{dtype}')
         self._rollout = getattr(self.lib, f'igt_rollout_batch_{dtype}')
         self._cart = getattr(self.lib, f'igt_cartesian_euler_{dtype}')
+        self._fstep = getattr(self.lib, f'igt_frenet_step_{dtype}')
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -187,6 +188,20 @@ class BatchSolver:
         mode, ptrs, keep = self._prep(arrs, shapes, dts)
         L.check(self._rollout(self._h, B, *ptrs, mode, self._stream_ptr(stream, False)))
         return dict(X=X, U=U, cost=cost, viol=viol)
+
+    def frenet_step(self, x, u, kparams, stream=None):
+        """One control step of the RK4 Frenet model for n states: x[n,7], u[n,2], kparams[n,3]
+        -> x_next[n,7]   (kinematic_bicycle_model_frenet.py:70-127)."""
+        n = int(x.shape[0])
+        dt = self.np_dtype
+        if _is_torch(x):
+            import torch
+            out = torch.empty((n, 7), dtype=x.dtype, device=x.device)
+        else:
+            out = np.empty((n, 7), dt)
+        mode, ptrs, keep = self._prep([x, u, kparams, out], [(n, 7), (n, 2), (n, 3), (n, 7)], [dt] * 4)
+        L.check(self._fstep(self._h, n, *ptrs, mode, self._stream_ptr(stream, mode == L.IGT_MEM_DEVICE)))
+        return out
 
     def cartesian_euler(self, z0, u, stream=None):
         """z0[n,4]=(x,y,psi,v), u[n,2,T] -> z[n,4,T+1]   (kinematic_bicycle_model.py:15-50)."""

@@ -172,6 +172,16 @@ int igt_rollout_batch_f64(igt_handle* h, int32_t B, const double* x0, const doub
                           const double* tv_sv, const double* enc, double* X_all, double* U_all,
                           double* cost_all, uint32_t* viol_all, int mem, void* stream);
 
+/* One control step of the RK4 Frenet bicycle model for n independent states -- the model
+ * object the reference's driver calls directly for warm-start extension and for the
+ * brake fallback (kinematic_bicycle_model_frenet.py:16-192 numpy branch; call sites
+ * utils.py:358, evaluate.py:520).  Uses the handle's dt, n_rk4, l_r, l_f.
+ *   x [n,7]   u [n,2] = (a, df)   kparams [n,3]   x_next [n,7] */
+int igt_frenet_step_f32(igt_handle* h, int32_t n, const float* x, const float* u, const float* kparams,
+                        float* x_next, int mem, void* stream);
+int igt_frenet_step_f64(igt_handle* h, int32_t n, const double* x, const double* u, const double* kparams,
+                        double* x_next, int mem, void* stream);
+
 /* 4-state Cartesian forward-Euler bicycle (kinematic_bicycle_model.py:15-50), the
  * model ReferenceGen.py steps to lay out reference paths.
  *   z0 [n,4] = (x, y, psi, v)   u [n,2,T] (a, df)   z_out [n,4,T+1] */

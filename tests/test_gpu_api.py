@@ -1,0 +1,130 @@
+"""-m gpu : the reference-shaped Python surface (MPC_Planner, model objects, predictor, closed loop)
+runs on the HIP path and agrees with the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import np_oracle as O
+from helpers import REL_TOL, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_frenet_step_entry_on_golden(golden_dir):
+    """igt_frenet_step_* against the reference-generated one-step transitions."""
+    import igtmpc
+    g = np.load(f'{golden_dir}/frenet_rk4_golden.npz')
+    x = g['X'][:, :, 3]
+    u = g['U'][:, :, 3]
+    want = g['X'][:, :, 4]
+    with igtmpc.BatchSolver(dtype='f64', N=1, C=64, n_obs=0) as s:
+        got = s.frenet_step(x, u, g['kp'])
+    assert rel_err(got, want).max() < 1e-12
+    with igtmpc.BatchSolver(dtype='f32', N=1, C=64, n_obs=0) as s:
+        got = s.frenet_step(x.astype(np.float32), u.astype(np.float32), g['kp'].astype(np.float32))
+    ref = O.frenet_rk4_step(x.astype(np.float32).astype(np.float64), u[:, 0].astype(np.float32).astype(np.float64),
+                            u[:, 1].astype(np.float32).astype(np.float64), g['kp'].astype(np.float32).astype(np.float64),
+                            O.Params())
+    bp = np.minimum(np.abs(ref[:, 2] - g['kp'][:, 0]), np.abs(ref[:, 2] - g['kp'][:, 1]))
+    assert rel_err(got, ref)[bp > 1e-2].max() < 2e-6
+
+
+def test_model_objects_match_reference_models(golden_dir):
+    import igtmpc
+    g = np.load(f'{golden_dir}/frenet_rk4_golden.npz')
+    m = igtmpc.KinematicBicycleModelFrenet(2.235, 2.235, 2.0, 0.1, discretization='rk4', mode='numpy', num_rk4_steps=4)
+    for i in (0, 1, 5, 17):
+        K = igtmpc.Curvature(*g['kp'][i])
+        st = igtmpc.VehicleReference(dict(zip(('x', 'y', 's', 'ey', 'epsi', 'v', 'heading'), g['x0'][i]), K=K))
+        for k in range(3):
+            st = m(st, igtmpc.VehicleAction({'a': g['U'][i, 0, k], 'df': g['U'][i, 1, k]}))
+        assert rel_err(st.state7(), g['X'][i, :, 3]).max() < 1e-12
+        assert st.K is K
+    c = np.load(f'{golden_dir}/cartesian_euler_golden.npz')
+    mc = igtmpc.KinematicBicycleModel(2.235, 2.235, 2.0, 0.1)
+    st = igtmpc.VehicleState({'x': c['z'][0, 0], 'y': c['z'][0, 1], 'heading': c['z'][0, 2], 'v': c['z'][0, 3]})
+    nx = mc(st, igtmpc.VehicleAction({'a': c['u'][0, 0], 'df': c['u'][0, 1]}))
+    assert rel_err([nx.x, nx.y, nx.heading, nx.v], c['z_next'][0]).max() < 1e-12
+    with pytest.raises(TypeError):
+        m(igtmpc.VehicleReference(dict(x=0, y=0, s=0, ey=0, epsi=0, v=1, heading=0, K=lambda s: 0)), igtmpc.VehicleAction({'a': 0, 'df': 0}))
+
+
+def _scene():
+    import igtmpc
+    from igtmpc import routes as R
+    routes = ['13', '23']
+    agents, refs = [], []
+    for r, s0, v0 in zip(routes, (12.0, 15.0), (3.0, 2.5)):
+        rid = R.ROUTE_ID[r]
+        xy = R.frenet2global(rid, s0)
+        K = igtmpc.Curvature.from_route(r)
+        agents.append({'type': 'CAV', 'state': igtmpc.VehicleReference(
+            {'x': xy[0], 'y': xy[1], 's': s0, 'ey': 0.02, 'epsi': -0.01, 'v': v0, 'heading': float(R.psi_ref(rid, s0)), 'K': K})})
+        kk = np.zeros(151)
+        if R.CONSTANTS[r].get('Kv'):
+            kk[40:80] = R.CONSTANTS[r]['Kv']
+        refs.append({'K': kk})
+    return routes, agents, refs
+
+
+def test_mpc_planner_call_sequence_matches_oracle():
+    """update_initial_condition -> update_predictions -> solve, as evaluate.py:470-482 drives it."""
+    import igtmpc
+    from igtmpc import routes as R
+    routes, agents, refs = _scene()
+    N = 20
+    pred = igtmpc.ConstantAccelerationModel(N=N, dt=0.1)
+    inputs = [igtmpc.VehicleAction({'a': 0.1, 'df': 0.0}) for _ in routes]
+    preds = pred.predict(agents, inputs, routes, refs)
+    assert len(preds) == 2 and len(preds[0]) == N + 1 and preds[0][0].x == agents[0]['state'].x
+    P = O.Params(N=N)
+    for i in range(2):
+        pl = igtmpc.MPC_Planner(N=N, dt=0.1, ca_radius=2.8, agents=agents, routes=routes, ref=refs, goals=None,
+                                road_dim=(11.4, 50), ds_right=8.6, index=i, num_rk4_steps=4, dtype='f64')
+        pl.update_initial_condition(agents[i], inputs[i])
+        pl.update_predictions(preds, raw_preds=preds)
+        x, u, ok = pl.solve()
+        assert pl.solve_time > 0 and pl.NN_query_time == -1 and 't_wall_total' in pl.sol.stats()
+        st = agents[i]['state']
+        x0 = np.array([st.state7()])
+        obs = np.array([[[[p.x for p in preds[1 - i]], [p.y for p in preds[1 - i]]]]])
+        ref = O.solve_batch(x0, np.array([[0.1, 0.0]]), np.array([pl.K.kparams]), np.array([0], np.uint32), obs,
+                            *pl.C_inf, P)
+        assert ok == (ref['status'][0] == 0)
+        if ok:
+            assert x.shape == (7, N + 1) and u.shape == (2, N)
+            assert rel_err(x, ref['x'][0]).max() < 1e-9 and rel_err(u, ref['u'][0]).max() < 1e-12
+        else:
+            assert x is None and u is None
+        # kparams derived from the reference-path curvature array agree with the route table
+        assert np.allclose(pl.K.kparams, R.kparams(R.ROUTE_ID[routes[i]]), rtol=1e-12, equal_nan=True)
+
+
+def test_compat_module_names_import():
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(here, 'igt-mpc-int_amd', 'igtmpc', 'compat'))
+    try:
+        from mpc import MPC_Planner                                   # noqa: F401
+        from VehicleReference import VehicleReference                 # noqa: F401
+        from kinematic_bicycle_model_frenet import KinematicBicycleModelFrenet  # noqa: F401
+        from constant_acceleration_model import ConstantAccelerationModel      # noqa: F401
+        from PredictorBase import PredictorBase                       # noqa: F401
+    finally:
+        sys.path.pop(0)
+
+
+def test_closed_loop_short_run():
+    from igtmpc.evaluate import run_closed_loop
+    r = run_closed_loop(sc=3, num_samples=6, N=20, T_sim=3.0)
+    assert r['x_data'].shape == (6, 14, 31) and np.isfinite(r['x_data']).all()
+    s = r['x_data'][:, 2::7, :]
+    assert (np.diff(s, axis=-1) >= -1e-6).all(), 'vehicles never reverse along their route'
+    assert (s[:, :, -1] > s[:, :, 0] + 1.0).all(), 'straight-crossing vehicles make progress in 3 s'
+    v = r['x_data'][:, 5::7, :]
+    assert v.max() <= 5 + 1e-3 and v.min() >= -1e-3
+    assert np.abs(r['x_data'][:, 3::7, :]).max() <= 0.2 + 1e-3            # |ey| <= 0.2 held in closed loop
+    # same seed -> same episodes
+    r2 = run_closed_loop(sc=3, num_samples=6, N=20, T_sim=3.0)
+    assert np.array_equal(r['x_data'], r2['x_data'])
