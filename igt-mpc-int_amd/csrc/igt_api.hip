@@ -41,6 +41,8 @@ struct igt_handle {
     bool net_set;
     void* d_stage;
     size_t stage_bytes;
+    void* d_work;          // per-slice partial arg-min workspace of the float path
+    size_t work_bytes;
     bool prof;
     hipEvent_t ev[3];
     bool ev_recorded;
@@ -88,6 +90,10 @@ igt::KP make_kp(const igt_params& p, int F) {
     k.dmin2 = p.d_min * p.d_min;               // mpc.py:226
     k.w_u = p.w_u;
     k.tol = p.feas_tol;
+    // stage-offset polynomials: short form while h * (largest angular rate a candidate can reach) stays
+    // small (igt_fast.h small_sincos2); v up to v_max + 2, |K| up to 0.25, sin(beta)/l_r <= 0.7/l_r
+    const double vhi = std::fmax(std::fabs(p.v_min), std::fabs(p.v_max)) + 2.0;
+    k.hi_order = (k.h * vhi * (0.7 / p.l_r + 0.25) > 0.12) ? 1 : 0;
     return k;
 }
 
@@ -160,6 +166,17 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
         return fail(IGT_E_INVALID, "mem must be IGT_MEM_DEVICE or IGT_MEM_HOST");
     }
 
+    {   // workspace for the per-slice partial arg-min (grows on first use; never shrinks)
+        const size_t W = ((size_t)p.C + 127) / 128, need = (size_t)B * W * 12 + 256;
+        if (need > h->work_bytes) {
+            HIPCHK(hipStreamSynchronize(st));
+            if (h->d_work) { HIPCHK(hipFree(h->d_work)); h->d_work = nullptr; h->work_bytes = 0; }
+            HIPCHK(hipMalloc(&h->d_work, need + need / 4));
+            h->work_bytes = need + need / 4;
+        }
+        A.part_J = reinterpret_cast<double*>(h->d_work);
+        A.part_c = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(h->d_work) + (((size_t)B * W * 8 + 255) & ~(size_t)255));
+    }
     if (h->prof) HIPCHK(hipEventRecord(h->ev[0], st));
     HIPCHK(igt::launch_search<T>(h->kp, B, A, h->nc, st));
     if (h->prof) HIPCHK(hipEventRecord(h->ev[1], st));
@@ -329,6 +346,7 @@ int igt_create(const igt_params* p, int device, igt_handle** out) {
     h->device = device;
     h->d_cinf = nullptr; h->d_table = nullptr; h->table_set = false; h->net_set = false;
     h->d_stage = nullptr; h->stage_bytes = 0;
+    h->d_work = nullptr; h->work_bytes = 0;
     h->prof = false; h->ev_recorded = false;
     h->nc = 2;
     if (const char* e = std::getenv("IGT_NC")) {
@@ -353,6 +371,7 @@ int igt_destroy(igt_handle* h) {
     if (h->d_cinf) (void)hipFree(h->d_cinf);
     if (h->d_table) (void)hipFree(h->d_table);
     if (h->d_stage) (void)hipFree(h->d_stage);
+    if (h->d_work) (void)hipFree(h->d_work);
     for (int i = 0; i < 3; ++i) (void)hipEventDestroy(h->ev[i]);
     (void)hipStreamDestroy(h->stream);
     delete h;

@@ -19,7 +19,7 @@
 namespace igt {
 
 struct KP {  // kernel parameters (by value -> SGPRs)
-    int N, n_rk4, C, n_obs, cand_mode, cost_mode, F, G;
+    int N, n_rk4, C, n_obs, cand_mode, cost_mode, F, G, hi_order;
     double dt, h, l_r, lr_ratio, v_min, v_max, a_min, a_max, df_max;
     double rate_a, rate_df, ey_lim, dmin2, w_u, tol;
 };

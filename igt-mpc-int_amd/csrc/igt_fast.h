@@ -1,0 +1,373 @@
+// igt_fast.h -- the float32 rollout of the search / emit / rollout-all kernels (gfx950).
+//
+// Two candidates of one lane are rolled together as the two halves of packed float2 values:
+// on gfx950 a wave issues one VALU instruction per ~2.3 cycles only when the next instruction
+// is independent of it (4.2 when it depends on it; tools/valu_microbench.hip), so a single
+// dependent chain leaves half the issue slots empty.  The pair gives every instruction an
+// independent neighbour (or packs both into one v_pk_* instruction).
+//
+// Arithmetic (same RK4 stages as kinematic_bicycle_model_frenet.py:107-119, float derivatives):
+//   * across control steps the state lives in double; inside a control step all sub-step
+//     arithmetic is float on "base + small offset" quantities:
+//       - K(s'): decided on d = float(s - b) + offset, relative to the break-point, with a
+//         clamped fma (step(d) = clamp(d*2^100 + 1, 0, 1)) instead of compare + select;
+//       - sin/cos of (beta+epsi') and (psi'+beta): rotation of the sub-step base pair by the stage
+//         offset (short polynomial); the (beta+epsi) base is rebuilt from the double epsi once per
+//         control step, the (psi+beta) base is carried by rotation and re-normalised once per step;
+//       - v and psi do not feed back: v_j and the psi offsets are closed-form, and the x,y rows
+//         collapse to one rotation of (A,B) = sum_j w_j v_j (cos,sin)(offset_j), including the
+//         reference's quirk that stage 4 sees psi + h/2*k3[6] (:111).
+//     increments are summed in float over the n_rk4 sub-steps and added to the double state once
+//     per control step (sum <= 0.5 m: rounding ~3e-8, far below the float-accumulator random walk
+//     of plain float32).
+//   * cost terms and verdicts are formed in float from the double step-boundary state and summed
+//     in double; controls are generated in double (u_out is the oracle's candidate to rounding).
+#pragma once
+#include "igt_device.h"
+
+namespace igt {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 splat(float x) { return (f2){x, x}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 rcp2(f2 x) { return (f2){__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+__device__ __forceinline__ f2 clamp01(f2 x) {
+    return (f2){__builtin_amdgcn_fmed3f(x.x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(x.y, 0.0f, 1.0f)};
+}
+
+// |d| <= ~0.12: sin to d^5, cos to d^4 (truncation 7e-11 / 4e-9)
+__device__ __forceinline__ void small_sincos2(f2 d, f2& sd, f2& cd) {
+    const f2 d2 = d * d;
+    const f2 p = fma2(d2, splat(1.0f / 120.0f), splat(-1.0f / 6.0f));
+    sd = fma2(d * d2, p, d);
+    const f2 q = fma2(d2, splat(1.0f / 24.0f), splat(-0.5f));
+    cd = fma2(d2, q, splat(1.0f));
+}
+// |d| <= 0.5 variant (coarser discretisations): two more terms
+__device__ __forceinline__ void small_sincos2_hi(f2 d, f2& sd, f2& cd) {
+    const f2 d2 = d * d;
+    f2 p = fma2(d2, splat(-1.0f / 5040.0f), splat(1.0f / 120.0f));
+    p = fma2(d2, p, splat(-1.0f / 6.0f));
+    sd = fma2(d * d2, p, d);
+    f2 q = fma2(d2, splat(1.0f / 40320.0f), splat(-1.0f / 720.0f));
+    q = fma2(d2, q, splat(1.0f / 24.0f));
+    q = fma2(d2, q, splat(-0.5f));
+    cd = fma2(d2, q, splat(1.0f));
+}
+
+__device__ __forceinline__ void rotate2(f2& s, f2& c, f2 sd, f2 cd) {
+    const f2 s_ = fma2(s, cd, c * sd);
+    const f2 c_ = fma2(c, cd, -(s * sd));
+    s = s_; c = c_;
+}
+
+// sin/cos of a double angle with float polynomials: reduce in double to r in [-pi/4, pi/4]
+__device__ __forceinline__ void sincos_reduced(double ang, float& s, float& c) {
+    const double kd = __builtin_rint(ang * 0.63661977236758134);       // 2/pi
+    const float r = (float)fma(-kd, 1.5707963267948966, ang);
+    const int q = (int)kd;
+    const float r2 = r * r;
+    float ps = fmaf(r2, 2.7557319e-6f, -1.9841270e-4f);                // 1/9!, -1/7!
+    ps = fmaf(r2, ps, 8.3333333e-3f);
+    ps = fmaf(r2, ps, -1.6666667e-1f);
+    const float sr = fmaf(r * r2, ps, r);
+    float pc = fmaf(r2, 2.4801587e-5f, -1.3888889e-3f);               // 1/8!, -1/6!
+    pc = fmaf(r2, pc, 4.1666667e-2f);
+    pc = fmaf(r2, pc, -0.5f);
+    const float cr = fmaf(r2, pc, 1.0f);
+    const float a = (q & 1) ? cr : sr;
+    const float b = (q & 1) ? sr : cr;
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
+}
+
+template <bool HI_ORDER>
+struct FastPair {
+    // per-scenario constants
+    float h, hh, h6, kv, inv_lr, lr_ratio, big;
+    double b0, b1, dt;
+    int n_rk4;
+
+    __device__ __forceinline__ void init(const KP& P, double b0_, double b1_, double kv_) {
+        h = (float)P.h; hh = (float)(P.h / 2); h6 = (float)(P.h / 6);
+        kv = (float)kv_; inv_lr = (float)(1.0 / P.l_r); lr_ratio = (float)P.lr_ratio;
+        big = 1.2676506e30f;      // 2^100
+        b0 = b0_; b1 = b1_; dt = P.dt; n_rk4 = P.n_rk4;
+    }
+    static __device__ __forceinline__ void ssc(f2 d, f2& sd, f2& cd) {
+        if (HI_ORDER) small_sincos2_hi(d, sd, cd); else small_sincos2(d, sd, cd);
+    }
+    // curvature of both candidates at break-point-relative arguments e + o*2^100
+    __device__ __forceinline__ f2 curv(f2 e0, f2 e1, f2 o) const {
+        // scalar v_fma_f32 ... clamp (the packed form cannot carry the clamp the compiler folds in)
+        const f2 c0 = {__builtin_amdgcn_fmed3f(fmaf(o.x, big, e0.x), 0.0f, 1.0f),
+                       __builtin_amdgcn_fmed3f(fmaf(o.y, big, e0.y), 0.0f, 1.0f)};
+        const f2 c1 = {__builtin_amdgcn_fmed3f(fmaf(o.x, big, e1.x), 0.0f, 1.0f),
+                       __builtin_amdgcn_fmed3f(fmaf(o.y, big, e1.y), 0.0f, 1.0f)};
+        return (c0 - c1) * splat(kv);
+    }
+
+    // One RK4 sub-step, general curvature.  In/out: base pairs (s1,c1)=(sin,cos)(beta+epsi),
+    // (s2,c2)=(sin,cos)(psi+beta); v1, ey, d0, d1 working values; acc_* increments of this control step.
+    struct Work {
+        f2 s1, c1, s2, c2, v1, ey, d0, d1, acc_s, acc_ey, acc_ep, acc_x, acc_y, acc_psi;
+    };
+
+    template <bool K0>
+    __device__ __forceinline__ void substep(f2 a, f2 ha, f2 sblr, Work& w) const {
+        const f2 H = splat(h), HH = splat(hh), H6 = splat(h6), BIG = splat(big), ONE = splat(1.0f), TWO = splat(2.0f);
+        const f2 v1 = w.v1;
+        const f2 v2 = v1 + ha;            // stages 2,3
+        const f2 v4 = v2 + ha;            // stage 4
+        const f2 s1 = w.s1, c1 = w.c1;
+        const f2 w1 = v1 * sblr, w2 = v2 * sblr, w4 = v4 * sblr;
+        // psi offsets h/2 w1 (stage 2), h/2 w2 (stages 3 AND 4, frenet.py:111)
+        f2 sd2, cd2, sd3, cd3;
+        ssc(HH * w1, sd2, cd2);
+        ssc(HH * w2, sd3, cd3);
+        f2 ds1, ds2, ds3, ds4, de1, de2, de3, de4, dp1, dp2, dp3, dp4, sd, cd, sa, ca;
+        if (K0) {
+            // K == 0 at every stage argument of every lane: 1 - K ey = 1, depsi = dpsi, so the
+            // (beta+epsi) stage offsets are the psi offsets.  Values are bit-identical to the
+            // general branch (it multiplies by rcp(1) = 1 and adds -ds*0).
+            ds1 = v1 * c1; de1 = v1 * s1; dp1 = w1;
+            sa = s1; ca = c1; rotate2(sa, ca, sd2, cd2);
+            ds2 = v2 * ca; de2 = v2 * sa; dp2 = w2;
+            sa = s1; ca = c1; rotate2(sa, ca, sd3, cd3);
+            ds3 = v2 * ca; de3 = v2 * sa; dp3 = w2;
+            ssc(H * w2, sd, cd);
+            sa = s1; ca = c1; rotate2(sa, ca, sd, cd);
+            ds4 = v4 * ca; de4 = v4 * sa; dp4 = w4;
+        } else {
+            const f2 e0 = fma2(w.d0, BIG, ONE), e1 = fma2(w.d1, BIG, ONE);
+            const f2 ey = w.ey;
+            // ---- stage 1
+            f2 K = (clamp01(e0) - clamp01(e1)) * splat(kv);
+            ds1 = v1 * c1 * rcp2(fma2(-K, ey, ONE));
+            de1 = v1 * s1;
+            dp1 = fma2(-ds1, K, w1);
+            // ---- stage 2: arguments base + h/2 k1
+            ssc(HH * dp1, sd, cd);
+            sa = s1; ca = c1; rotate2(sa, ca, sd, cd);
+            K = curv(e0, e1, HH * ds1);
+            ds2 = v2 * ca * rcp2(fma2(-K, fma2(HH, de1, ey), ONE));
+            de2 = v2 * sa;
+            dp2 = fma2(-ds2, K, w2);
+            // ---- stage 3: base + h/2 k2
+            ssc(HH * dp2, sd, cd);
+            sa = s1; ca = c1; rotate2(sa, ca, sd, cd);
+            K = curv(e0, e1, HH * ds2);
+            ds3 = v2 * ca * rcp2(fma2(-K, fma2(HH, de2, ey), ONE));
+            de3 = v2 * sa;
+            dp3 = fma2(-ds3, K, w2);
+            // ---- stage 4: base + h k3
+            ssc(H * dp3, sd, cd);
+            sa = s1; ca = c1; rotate2(sa, ca, sd, cd);
+            K = curv(e0, e1, H * ds3);
+            ds4 = v4 * ca * rcp2(fma2(-K, fma2(H, de3, ey), ONE));
+            de4 = v4 * sa;
+            dp4 = fma2(-ds4, K, w4);
+        }
+        // ---- Cartesian rows collapse to one rotation of (A,B)
+        const f2 v34 = fma2(TWO, v2, v4);
+        const f2 tv2 = TWO * v2;
+        const f2 A = fma2(v34, cd3, fma2(tv2, cd2, v1));
+        const f2 Bq = fma2(v34, sd3, tv2 * sd2);
+        const f2 dx = fma2(w.c2, A, -(w.s2 * Bq));
+        const f2 dy = fma2(w.s2, A, w.c2 * Bq);
+        // ---- combine (frenet.py:113-119)
+        const f2 is = H6 * (ds1 + TWO * ds2 + TWO * ds3 + ds4);
+        const f2 ie = H6 * (de1 + TWO * de2 + TWO * de3 + de4);
+        const f2 ip = H6 * (dp1 + TWO * dp2 + TWO * dp3 + dp4);
+        w.acc_s += is; w.acc_ey += ie; w.acc_ep += ip;
+        w.acc_x = fma2(H6, dx, w.acc_x);
+        w.acc_y = fma2(H6, dy, w.acc_y);
+        w.acc_psi = fma2(H6, w1 + splat(4.0f) * w2 + w4, w.acc_psi);
+        w.d0 += is; w.d1 += is; w.ey += ie; w.v1 = v4;
+        // ---- base pairs for the next sub-step: psi advanced by h*w2 = twice the stage-3 offset
+        ssc(ip, sd, cd);
+        rotate2(w.s1, w.c1, sd, cd);
+        const f2 s22 = TWO * sd3 * cd3, c22 = fma2(-TWO * sd3, sd3, ONE);
+        rotate2(w.s2, w.c2, s22, c22);
+    }
+
+    // n_rk4 sub-steps of one control step.  The K == 0 branch is taken when it is provably exact for the
+    // whole wave (straight route, or every lane's stage arguments stay on one side of both break-points).
+    // UNIFORM = false (one lane per scenario, emit): lanes disagree, so only the general branch is used
+    // (bit-identical values either way).
+    template <bool UNIFORM>
+    __device__ __forceinline__ void substeps(f2 a, f2 sblr, Work& w) const {
+        const f2 ha = splat(hh) * a;
+        if (!UNIFORM) {
+            for (int j = 0; j < n_rk4; ++j) substep<false>(a, ha, sblr, w);
+            return;
+        }
+        if (kv == 0.0f) {                      // straight route: scalar condition, hoisted
+            for (int j = 0; j < n_rk4; ++j) substep<true>(a, ha, sblr, w);
+            return;
+        }
+        for (int j = 0; j < n_rk4; ++j) {
+            // travel bound of this sub-step: |o| <= h |ds| <= 1.5 h (|v| + |h a|)
+            const f2 m = splat(1.5f * h) * (__builtin_elementwise_abs(w.v1) + splat(2.0f) * __builtin_elementwise_abs(ha));
+            const f2 lo = w.d0 + m, hi = w.d1 - m;
+            const bool clear = ((lo.x < 0.0f) | (hi.x > 0.0f)) & ((lo.y < 0.0f) | (hi.y > 0.0f));
+            if (__all(clear)) substep<true>(a, ha, sblr, w);
+            else substep<false>(a, ha, sblr, w);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// one pass over a PAIR of candidates of one scenario
+// ---------------------------------------------------------------------------------------
+// LATTICE: both candidates share the steering profile (c and c+64 have the same j) and satisfy the input
+// box / rate limits by construction; otherwise controls come from the table and are checked.
+// BOOK = false (emit): cost and verdicts are skipped, only the trajectory is produced.
+template <bool LATTICE, bool HI_ORDER, bool BOOK, bool UNIFORM, typename T, class Sink>
+__device__ __forceinline__ void rollout_pair(const KP& P, const Scenario<T>& S, const int (&cidx)[2],
+                                             const double* __restrict__ table,
+                                             const double* __restrict__ cinf, Sink& sink, double (&Jout)[2],
+                                             unsigned (&vout)[2], double (&sN)[2], double (&vN)[2]) {
+    typedef FastPair<HI_ORDER> FP;
+    FP fp;
+    fp.init(P, S.b0, S.b1, S.kv);
+    double s[2], ey[2], ep[2], v[2], x[2], y[2], psi[2], J[2], a_d[2], df_d[2], da[2], ddf = 0.0;
+    unsigned viol[2];
+    const float ey_lim = (float)P.ey_lim, tol = (float)P.tol, vmin = (float)P.v_min, vmax = (float)P.v_max;
+    const float w_u = (float)P.w_u, dmin2 = (float)P.dmin2, ratio2 = fp.lr_ratio * fp.lr_ratio;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        x[q] = S.x0[0]; y[q] = S.x0[1]; s[q] = S.x0[2]; ey[q] = S.x0[3]; ep[q] = S.x0[4]; v[q] = S.x0[5]; psi[q] = S.x0[6];
+        a_d[q] = S.a_prev; df_d[q] = S.df_prev;
+        if (LATTICE) {
+            // da_i = -ra + (2 ra) i/(G-1), ddf_j likewise (oracle candidates_lattice)
+            const int i = cidx[q] / P.G, j = cidx[q] - i * P.G;
+            da[q] = -P.rate_a + (2 * P.rate_a) * (double)i / (double)(P.G - 1);
+            if (q == 0) ddf = -P.rate_df + (2 * P.rate_df) * (double)j / (double)(P.G - 1);
+        }
+        J[q] = 0.0; viol[q] = 0;
+        sink.state(q, 0, S.x0);
+    }
+    // (sin,cos)(psi_0): the same for every candidate of the scenario
+    float sp0, cp0;
+    sincos_reduced(S.x0[6], sp0, cp0);
+    typename FP::Work w;
+    w.s2 = splat(sp0); w.c2 = splat(cp0);      // carried as (sin,cos)(psi + beta_k); beta_{-1} = 0
+    f2 cb_prev = splat(1.0f), sb_prev = splat(0.0f);
+
+    for (int k = 0; k < P.N; ++k) {
+        // ---- controls of step k (double)
+        f2 a, cb, sb, tu;
+        if (LATTICE) {
+            df_d[0] = clampd(df_d[0] + ddf, -P.df_max, P.df_max);
+            df_d[1] = df_d[0];
+            a_d[0] = clampd(a_d[0] + da[0], P.a_min, P.a_max);
+            a_d[1] = clampd(a_d[1] + da[1], P.a_min, P.a_max);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const double an = table[((size_t)cidx[q] * 2 + 0) * P.N + k];
+                const double dn = table[((size_t)cidx[q] * 2 + 1) * P.N + k];
+                // input-rate (mpc.py:301-312, u_{-1} = u_prev) and input box (mpc.py:318-321)
+                if (BOOK) {
+                    if (fmax(fabs(an - a_d[q]) - P.rate_a, fabs(dn - df_d[q]) - P.rate_df) > P.tol) viol[q] |= VIOL_RATE;
+                    if (fmax(fmax(P.a_min - an, an - P.a_max), fmax(-P.df_max - dn, dn - P.df_max)) > P.tol)
+                        viol[q] |= VIOL_BOX_U;
+                }
+                a_d[q] = an; df_d[q] = dn;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            sink.ctrl(q, k, a_d[q], df_d[q]);
+            a[q] = (float)a_d[q];
+            if (!LATTICE || q == 0) {
+                // beta = atan(r tan df), r = l_r/(l_f+l_r):  cos(beta) = c/n, sin(beta) = r s/n,
+                // n = sqrt(c^2 + r^2 s^2), (s,c) = (sin,cos)(df)   (|df| < pi/2)
+                float sdf, cdf;
+                sincos_reduced(df_d[q], sdf, cdf);
+                const float n = rsqrtf(fmaf(ratio2 * sdf, sdf, cdf * cdf));
+                cb[q] = cdf * n;
+                sb[q] = fp.lr_ratio * sdf * n;
+                const float dff = (float)df_d[q];
+                tu[q] = dff * dff;
+            } else {
+                cb[q] = cb[0]; sb[q] = sb[0]; tu[q] = tu[0];
+            }
+        }
+        const f2 sblr = sb * splat(fp.inv_lr);
+        tu = splat(w_u) * fma2(a, a, tu);                              // mpc.py:362
+        // ---- bookkeeping of state k + float working set of this control step
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            w.ey[q] = (float)ey[q];
+            w.v1[q] = (float)v[q];
+            if (BOOK) {
+                const float epf = (float)ep[q];
+                const float t = fmaf(w.ey[q], w.ey[q], fmaf(epf, epf, tu[q]));    // mpc.py:362-364
+                J[q] += (double)t;
+                if (fabsf(w.ey[q]) - ey_lim > tol) viol[q] |= VIOL_EY;          // mpc.py:296-299
+                if (fmaxf(vmin - w.v1[q], w.v1[q] - vmax) > tol) viol[q] |= VIOL_BOX_V;   // mpc.py:316-317 (k < N)
+                if (k == P.N - 1) viol[q] |= terminal_viol(P, v[q], a_d[q], cinf);       // mpc.py:177-180
+            }
+            float se, ce;
+            sincos_reduced(ep[q], se, ce);
+            w.s1[q] = se; w.c1[q] = ce;
+            w.d0[q] = (float)(s[q] - fp.b0);
+            w.d1[q] = (float)(s[q] - fp.b1);
+        }
+        if (BOOK && k >= 1) {                                          // collision, mpc.py:223-226
+            for (int o = 0; o < P.n_obs; ++o) {
+                const double ox = (double)S.obs[(o * 2 + 0) * (P.N + 1) + k];
+                const double oy = (double)S.obs[(o * 2 + 1) * (P.N + 1) + k];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float dx = (float)(x[q] - ox), dy = (float)(y[q] - oy);
+                    if (dmin2 - fmaf(dx, dx, dy * dy) > tol) viol[q] |= VIOL_COLLISION;
+                }
+            }
+        }
+        rotate2(w.s1, w.c1, sb, cb);                                   // (sin,cos)(beta + epsi)
+        // (sin,cos)(psi + beta_k) from (psi + beta_{k-1}): rotate by beta_k - beta_{k-1}, re-normalise
+        {
+            const f2 sdb = fma2(sb, cb_prev, -(cb * sb_prev));
+            const f2 cdb = fma2(cb, cb_prev, sb * sb_prev);
+            rotate2(w.s2, w.c2, sdb, cdb);
+            const f2 n = fma2(w.s2, w.s2, w.c2 * w.c2);
+            const f2 r = fma2(n, splat(-0.5f), splat(1.5f));
+            w.s2 *= r; w.c2 *= r;
+            cb_prev = cb; sb_prev = sb;
+        }
+        w.acc_s = splat(0.f); w.acc_ey = splat(0.f); w.acc_ep = splat(0.f);
+        w.acc_x = splat(0.f); w.acc_y = splat(0.f); w.acc_psi = splat(0.f);
+        fp.template substeps<UNIFORM>(a, sblr, w);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            s[q] += (double)w.acc_s[q]; ey[q] += (double)w.acc_ey[q]; ep[q] += (double)w.acc_ep[q];
+            x[q] += (double)w.acc_x[q]; y[q] += (double)w.acc_y[q]; psi[q] += (double)w.acc_psi[q];
+            v[q] = fma(fp.dt, a_d[q], v[q]);
+            const double nxt[7] = {x[q], y[q], s[q], ey[q], ep[q], v[q], psi[q]};
+            sink.state(q, k + 1, nxt);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2 && BOOK; ++q) {
+        const float epf = (float)ep[q], eyq = (float)ey[q];
+        J[q] += (double)fmaf(eyq, eyq, epf * epf);
+        if (fabsf(eyq) - ey_lim > tol) viol[q] |= VIOL_EY;
+        for (int o = 0; o < P.n_obs; ++o) {
+            const float dx = (float)(x[q] - (double)S.obs[(o * 2 + 0) * (P.N + 1) + P.N]);
+            const float dy = (float)(y[q] - (double)S.obs[(o * 2 + 1) * (P.N + 1) + P.N]);
+            if (dmin2 - fmaf(dx, dx, dy * dy) > tol) viol[q] |= VIOL_COLLISION;
+        }
+        if (!(fabs(x[q]) < 1e300 && fabs(y[q]) < 1e300 && fabs(s[q]) < 1e300 && fabs(ey[q]) < 1e300 &&
+              fabs(ep[q]) < 1e300 && fabs(psi[q]) < 1e300))
+            viol[q] |= VIOL_NONFINITE;
+        sN[q] = s[q]; vN[q] = v[q];
+        Jout[q] = J[q]; vout[q] = viol[q];
+    }
+    if (!BOOK) { Jout[0] = Jout[1] = 0.0; vout[0] = vout[1] = 0; sN[0] = sN[1] = 0.0; vN[0] = vN[1] = 0.0; }
+}
+
+}  // namespace igt

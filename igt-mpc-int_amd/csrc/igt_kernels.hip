@@ -8,6 +8,7 @@
 //   rollout_all_kernel   debug/parity: every candidate's trajectory, cost and verdict bits.
 //   cartesian_euler_kernel   kinematic_bicycle_model.py:15-50, one lane per trajectory.
 #include "igt_device.h"
+#include "igt_fast.h"
 #include "igt_launch.h"
 
 namespace igt {
@@ -155,6 +156,146 @@ __global__ __launch_bounds__(256) void rollout_all_kernel(KP P, int B, const T* 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// float32 path: two candidates per lane rolled as a packed pair (igt_fast.h)
+// ---------------------------------------------------------------------------------------
+template <typename T>
+struct PairSink {
+    T* x[2];
+    T* u[2];
+    int N;
+    __device__ __forceinline__ void ctrl(int q, int k, double a, double df) {
+        if (u[q]) { u[q][k] = (T)a; u[q][N + k] = (T)df; }
+    }
+    __device__ __forceinline__ void state(int q, int k, const double (&st)[7]) {
+        if (x[q]) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) x[q][i * (N + 1) + k] = (T)st[i];
+        }
+    }
+};
+
+// One wave = one (scenario, 128-candidate slice): W = ceil(C/128) waves per scenario, so a B = 4096 batch is
+// 8192 independent waves (better balance over the 2048 wave slots than 4096 double-length ones).  Each wave
+// stores its slice's best (J, c); emit_fast_kernel reduces the W partials (ties -> lowest candidate index).
+template <bool SHARED_DF, bool HI>
+__global__ __launch_bounds__(256) void search_fast_kernel(KP P, int B, int W, const float* __restrict__ x0,
+                                                          const float* __restrict__ u_prev,
+                                                          const float* __restrict__ kparams,
+                                                          const uint32_t* __restrict__ flags,
+                                                          const float* __restrict__ obs,
+                                                          const double* __restrict__ table,
+                                                          const double* __restrict__ cinf,
+                                                          double* __restrict__ part_J, int32_t* __restrict__ part_c) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int gw = blockIdx.x * 4 + wave;
+    if (gw >= B * W) return;  // wave-uniform
+    const int b = gw / W, p = gw - b * W;
+    const int lane = threadIdx.x & 63;
+    Scenario<float> S;
+    load_scenario<float>(S, P, b, x0, u_prev, kparams, flags, obs);
+    NullSink sink;
+    const int chunks = P.C / 64;
+    // an odd number of 64-candidate chunks: the last slice rolls its chunk twice (harmless duplicate)
+    const int cidx[2] = {(2 * p) * 64 + lane, (2 * p + 1 < chunks ? 2 * p + 1 : 2 * p) * 64 + lane};
+    double J[2], sN[2], vN[2];
+    unsigned viol[2];
+    rollout_pair<SHARED_DF, HI, true, true, float>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
+    double bestJ = 0.0;
+    int bestC = -1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const double Jq = J[q] - (sN[q] - S.x0[2]);  // mpc.py:372
+        const bool ok = (viol[q] == 0) && finite_d(Jq);
+        if (ok && (bestC < 0 || Jq < bestJ)) { bestJ = Jq; bestC = cidx[q]; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double oJ = __shfl_xor(bestJ, off, 64);
+        const int oC = __shfl_xor(bestC, off, 64);
+        const bool take = (oC >= 0) && (bestC < 0 || oJ < bestJ || (oJ == bestJ && oC < bestC));
+        if (take) { bestJ = oJ; bestC = oC; }
+    }
+    if (lane == 0) { part_J[gw] = bestJ; part_c[gw] = bestC; }
+}
+
+template <bool LATTICE, bool HI>
+__global__ __launch_bounds__(64) void emit_fast_kernel(KP P, int B, int W, const float* __restrict__ x0,
+                                                       const float* __restrict__ u_prev,
+                                                       const float* __restrict__ kparams,
+                                                       const uint32_t* __restrict__ flags,
+                                                       const float* __restrict__ obs,
+                                                       const double* __restrict__ table,
+                                                       const double* __restrict__ cinf,
+                                                       const double* __restrict__ part_J,
+                                                       const int32_t* __restrict__ part_c,
+                                                       float* __restrict__ cost_out, int32_t* __restrict__ argmin_out,
+                                                       int32_t* __restrict__ status_out, float* __restrict__ x_out,
+                                                       float* __restrict__ u_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    // final arg-min over the W slices (slices are ordered by candidate index: strict '<' keeps the lowest)
+    double bestJ = 0.0;
+    int c = -1;
+    for (int w = 0; w < W; ++w) {
+        const int cw = part_c[(size_t)b * W + w];
+        const double Jw = part_J[(size_t)b * W + w];
+        if (cw >= 0 && (c < 0 || Jw < bestJ)) { bestJ = Jw; c = cw; }
+    }
+    cost_out[b] = c >= 0 ? (float)bestJ : INFINITY;
+    argmin_out[b] = c;
+    status_out[b] = c >= 0 ? 0 : 1;
+    float* xo = x_out + (size_t)b * 7 * (P.N + 1);
+    float* uo = u_out + (size_t)b * 2 * P.N;
+    if (c < 0) {  // is_opt False (mpc.py:402-406): no trajectory
+        for (int i = 0; i < 7 * (P.N + 1); ++i) xo[i] = NAN;
+        for (int i = 0; i < 2 * P.N; ++i) uo[i] = NAN;
+        return;
+    }
+    Scenario<float> S;
+    load_scenario<float>(S, P, b, x0, u_prev, kparams, flags, obs);
+    PairSink<float> sink{{xo, nullptr}, {uo, nullptr}, P.N};
+    const int cidx[2] = {c, c};
+    double J[2], sN[2], vN[2];
+    unsigned viol[2];
+    rollout_pair<LATTICE, HI, false, false, float>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
+}
+
+template <bool LATTICE, bool HI>
+__global__ __launch_bounds__(256) void rollout_all_fast_kernel(KP P, int B, const float* __restrict__ x0,
+                                                               const float* __restrict__ u_prev,
+                                                               const float* __restrict__ kparams,
+                                                               const uint32_t* __restrict__ flags,
+                                                               const float* __restrict__ obs,
+                                                               const double* __restrict__ table,
+                                                               const double* __restrict__ cinf,
+                                                               float* __restrict__ X_all, float* __restrict__ U_all,
+                                                               float* __restrict__ cost_all,
+                                                               uint32_t* __restrict__ viol_all) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    Scenario<float> S;
+    load_scenario<float>(S, P, b, x0, u_prev, kparams, flags, obs);
+    for (int c = lane; c < P.C; c += 128) {
+        const int cidx[2] = {c, c + 64 < P.C ? c + 64 : c};
+        const size_t bc0 = (size_t)b * P.C + c, bc1 = (size_t)b * P.C + cidx[1];
+        PairSink<float> sink{{X_all ? X_all + bc0 * 7 * (P.N + 1) : nullptr, X_all ? X_all + bc1 * 7 * (P.N + 1) : nullptr},
+                             {U_all ? U_all + bc0 * 2 * P.N : nullptr, U_all ? U_all + bc1 * 2 * P.N : nullptr}, P.N};
+        double J[2], sN[2], vN[2];
+        unsigned viol[2];
+        rollout_pair<LATTICE, HI, true, true, float>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const double Jq = J[q] - (sN[q] - S.x0[2]);
+            if (!finite_d(Jq)) viol[q] |= VIOL_NONFINITE;
+            cost_all[q ? bc1 : bc0] = (float)Jq;
+            viol_all[q ? bc1 : bc0] = viol[q];
+        }
+    }
+}
+
 // one control step for n independent states (kinematic_bicycle_model_frenet.py:70-127)
 template <class Stepper, typename T>
 __global__ __launch_bounds__(256) void frenet_step_kernel(KP P, int n, const T* __restrict__ x,
@@ -221,13 +362,19 @@ static hipError_t launch_search_nc(const KP& P, int B, const SolveArgs<T>& A, hi
     return hipGetLastError();
 }
 
+template <bool SHARED, bool HI>
+static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>& A, hipStream_t st) {
+    const int W = (P.C + 127) / 128;
+    hipLaunchKernelGGL((search_fast_kernel<SHARED, HI>), dim3(((size_t)B * W + 3) / 4), dim3(256), 0, st, P, B, W, A.x0,
+                       A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.part_J, A.part_c);
+    return hipGetLastError();
+}
 template <>
 hipError_t launch_search<float>(const KP& P, int B, const SolveArgs<float>& A, int nc, hipStream_t st) {
-    switch (nc) {
-        case 1: return launch_search_nc<FastStepper, float, 1>(P, B, A, st);
-        case 2: return launch_search_nc<FastStepper, float, 2>(P, B, A, st);
-        default: return launch_search_nc<FastStepper, float, 4>(P, B, A, st);
-    }
+    (void)nc;
+    const bool shared = P.cand_mode == CAND_LATTICE;
+    if (P.hi_order) return shared ? launch_search_fast<true, true>(P, B, A, st) : launch_search_fast<false, true>(P, B, A, st);
+    return shared ? launch_search_fast<true, false>(P, B, A, st) : launch_search_fast<false, false>(P, B, A, st);
 }
 template <>
 hipError_t launch_search<double>(const KP& P, int B, const SolveArgs<double>& A, int nc, hipStream_t st) {
@@ -235,11 +382,19 @@ hipError_t launch_search<double>(const KP& P, int B, const SolveArgs<double>& A,
     return launch_search_nc<ExactStepper<double>, double, 1>(P, B, A, st);
 }
 
+template <bool LATTICE, bool HI>
+static hipError_t launch_emit_fast(const KP& P, int B, const SolveArgs<float>& A, hipStream_t st) {
+    const int W = (P.C + 127) / 128;
+    hipLaunchKernelGGL((emit_fast_kernel<LATTICE, HI>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, W, A.x0, A.u_prev,
+                       A.kparams, A.flags, A.obs, A.table, A.cinf, A.part_J, A.part_c, A.cost_out, A.argmin_out,
+                       A.status_out, A.x_out, A.u_out);
+    return hipGetLastError();
+}
 template <>
 hipError_t launch_emit<float>(const KP& P, int B, const SolveArgs<float>& A, hipStream_t st) {
-    hipLaunchKernelGGL((emit_kernel<FastStepper, float>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, A.x0, A.u_prev,
-                       A.kparams, A.flags, A.obs, A.table, A.cinf, A.argmin_out, A.x_out, A.u_out);
-    return hipGetLastError();
+    const bool lat = P.cand_mode == CAND_LATTICE;
+    if (P.hi_order) return lat ? launch_emit_fast<true, true>(P, B, A, st) : launch_emit_fast<false, true>(P, B, A, st);
+    return lat ? launch_emit_fast<true, false>(P, B, A, st) : launch_emit_fast<false, false>(P, B, A, st);
 }
 template <>
 hipError_t launch_emit<double>(const KP& P, int B, const SolveArgs<double>& A, hipStream_t st) {
@@ -248,12 +403,22 @@ hipError_t launch_emit<double>(const KP& P, int B, const SolveArgs<double>& A, h
     return hipGetLastError();
 }
 
+template <bool LATTICE, bool HI>
+static hipError_t launch_rollout_all_fast(const KP& P, int B, const SolveArgs<float>& A, float* X_all, float* U_all,
+                                          float* cost_all, uint32_t* viol_all, hipStream_t st) {
+    hipLaunchKernelGGL((rollout_all_fast_kernel<LATTICE, HI>), dim3((B + 3) / 4), dim3(256), 0, st, P, B, A.x0, A.u_prev,
+                       A.kparams, A.flags, A.obs, A.table, A.cinf, X_all, U_all, cost_all, viol_all);
+    return hipGetLastError();
+}
 template <>
 hipError_t launch_rollout_all<float>(const KP& P, int B, const SolveArgs<float>& A, float* X_all, float* U_all,
                                      float* cost_all, uint32_t* viol_all, hipStream_t st) {
-    hipLaunchKernelGGL((rollout_all_kernel<FastStepper, float>), dim3((B + 3) / 4), dim3(256), 0, st, P, B, A.x0,
-                       A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, X_all, U_all, cost_all, viol_all);
-    return hipGetLastError();
+    const bool lat = P.cand_mode == CAND_LATTICE;
+    if (P.hi_order)
+        return lat ? launch_rollout_all_fast<true, true>(P, B, A, X_all, U_all, cost_all, viol_all, st)
+                   : launch_rollout_all_fast<false, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+    return lat ? launch_rollout_all_fast<true, false>(P, B, A, X_all, U_all, cost_all, viol_all, st)
+               : launch_rollout_all_fast<false, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
 }
 template <>
 hipError_t launch_rollout_all<double>(const KP& P, int B, const SolveArgs<double>& A, double* X_all, double* U_all,

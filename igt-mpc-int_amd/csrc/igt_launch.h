@@ -22,6 +22,8 @@ struct SolveArgs {   // all device pointers
     T* cost_out;
     int32_t* argmin_out;
     int32_t* status_out;
+    double* part_J;        // [B, ceil(C/128)] per-slice best cost   (float path workspace)
+    int32_t* part_c;       // [B, ceil(C/128)] per-slice best candidate
 };
 
 template <typename T> hipError_t launch_search(const KP& P, int B, const SolveArgs<T>& A, int nc, hipStream_t st);

@@ -14,10 +14,14 @@ from igtmpc import BatchSolver  # noqa: E402
 from igtmpc.scenarios import make_batch  # noqa: E402
 
 
-def run(dtype, B, nc, iters=5):
+def run(dtype, B, nc, iters=5, straight=None):
     os.environ['IGT_NC'] = str(nc)
     npdt = np.float32 if dtype == 'f32' else np.float64
     b = make_batch(B, dtype=npdt)
+    if straight is True:
+        b['kparams'][:] = (np.inf, np.inf, 0.0)
+    elif straight is False:
+        b['kparams'][:] = (19.3, 32.8088, 0.11627907)
     args = [torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda()
             for a in (b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy'])]
     with BatchSolver(dtype=dtype) as s:
@@ -35,13 +39,14 @@ def run(dtype, B, nc, iters=5):
             te.append(e)
         st = out['status'].cpu().numpy()
     ms, me, mw = np.median(ts), np.median(te), np.median(wall) * 1e3
-    print(f'{dtype} B={B:6d} NC={nc}: search {ms:8.3f} ms  emit {me:7.3f} ms  wall {mw:8.3f} ms  '
+    print(f'{dtype} B={B:6d} straight={straight}: search {ms:8.3f} ms  emit {me:7.3f} ms  wall {mw:8.3f} ms  '
           f'-> {B / (ms + me) * 1e3 / 1e6:7.3f} M solves/s (kernels)  feasible {np.mean(st == 0):.2f}', flush=True)
 
 
 if __name__ == '__main__':
-    for nc in (1, 2, 4):
-        run('f32', 4096, nc)
-    for nc in (1, 2, 4):
-        run('f32', 65536, nc)
-    run('f64', 4096, 1, iters=2)
+    run('f32', 4096, 2)
+    run('f32', 65536, 2)
+    run('f32', 65536, 2, straight=True)
+    run('f32', 65536, 2, straight=False)
+    if len(sys.argv) > 1:
+        run('f64', 4096, 1, iters=2)

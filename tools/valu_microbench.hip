@@ -41,6 +41,23 @@ __global__ __launch_bounds__(256) void k(float* out, float seed) {
             a4 = a4 > 0.5f ? a5 : a6; a5 = a5 > 0.5f ? a6 : a7; a6 = a6 > 0.5f ? a7 : a0; a7 = a7 > 0.5f ? a0 : a1;
         } else if (OP == 9) {  // 2 sin via v_sin_f32 (native)
             a0 = __sinf(a0); a1 = __sinf(a1);
+        } else if (OP == 10) {  // ONE dependent chain of 8 v_pk_fma_f32
+            p0 = __builtin_elementwise_fma(p0, m, c); p0 = __builtin_elementwise_fma(p0, m, c); p0 = __builtin_elementwise_fma(p0, m, c); p0 = __builtin_elementwise_fma(p0, m, c);
+            p0 = __builtin_elementwise_fma(p0, m, c); p0 = __builtin_elementwise_fma(p0, m, c); p0 = __builtin_elementwise_fma(p0, m, c); p0 = __builtin_elementwise_fma(p0, m, c);
+        } else if (OP == 11) {  // TWO interleaved dependent chains of v_fma_f32 (4 + 4)
+            a0 = fmaf(a0, 0.999f, 0.5f); a1 = fmaf(a1, 0.999f, 0.5f); a0 = fmaf(a0, 0.999f, 0.5f); a1 = fmaf(a1, 0.999f, 0.5f);
+            a0 = fmaf(a0, 0.999f, 0.5f); a1 = fmaf(a1, 0.999f, 0.5f); a0 = fmaf(a0, 0.999f, 0.5f); a1 = fmaf(a1, 0.999f, 0.5f);
+        } else if (OP == 12) {  // TWO interleaved dependent chains of v_pk_fma_f32 (4 + 4)
+            p0 = __builtin_elementwise_fma(p0, m, c); p1 = __builtin_elementwise_fma(p1, m, c); p0 = __builtin_elementwise_fma(p0, m, c); p1 = __builtin_elementwise_fma(p1, m, c);
+            p0 = __builtin_elementwise_fma(p0, m, c); p1 = __builtin_elementwise_fma(p1, m, c); p0 = __builtin_elementwise_fma(p0, m, c); p1 = __builtin_elementwise_fma(p1, m, c);
+        } else if (OP == 13) {  // FOUR interleaved dependent chains of v_fma_f32 (2 each)
+            a0 = fmaf(a0, 0.999f, 0.5f); a1 = fmaf(a1, 0.999f, 0.5f); a2 = fmaf(a2, 0.999f, 0.5f); a3 = fmaf(a3, 0.999f, 0.5f);
+            a0 = fmaf(a0, 0.999f, 0.5f); a1 = fmaf(a1, 0.999f, 0.5f); a2 = fmaf(a2, 0.999f, 0.5f); a3 = fmaf(a3, 0.999f, 0.5f);
+        } else if (OP == 14) {  // v_fma_f32 with clamp, 8 independent
+            a0 = __builtin_amdgcn_fmed3f(fmaf(a0, 0.999f, 0.5f), 0.f, 1.f); a1 = __builtin_amdgcn_fmed3f(fmaf(a1, 0.999f, 0.5f), 0.f, 1.f);
+            a2 = __builtin_amdgcn_fmed3f(fmaf(a2, 0.999f, 0.5f), 0.f, 1.f); a3 = __builtin_amdgcn_fmed3f(fmaf(a3, 0.999f, 0.5f), 0.f, 1.f);
+            a4 = __builtin_amdgcn_fmed3f(fmaf(a4, 0.999f, 0.5f), 0.f, 1.f); a5 = __builtin_amdgcn_fmed3f(fmaf(a5, 0.999f, 0.5f), 0.f, 1.f);
+            a6 = __builtin_amdgcn_fmed3f(fmaf(a6, 0.999f, 0.5f), 0.f, 1.f); a7 = __builtin_amdgcn_fmed3f(fmaf(a7, 0.999f, 0.5f), 0.f, 1.f);
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(d0 + d1 + d2 + d3) + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
@@ -66,7 +83,7 @@ int bench(const char* name, double ops_per_iter, int waves_per_simd) {
 }
 
 int main() {
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {1, 2, 3, 4, 8}) {
         bench<0>("v_fma_f32 x8 indep", 8, w);
         bench<7>("v_fma_f32 x8 dependent", 8, w);
         bench<1>("v_pk_fma_f32 x4", 4, w);
@@ -75,8 +92,11 @@ int main() {
         bench<6>("cvt_f64_f32+add_f64 x4", 8, w);
         bench<3>("v_rcp_f32 x8", 8, w);
         bench<8>("cmp+cndmask x8", 16, w);
-        bench<9>("__sinf x2 (per call)", 2, w);
-        bench<4>("sincosf x2 (per call)", 2, w);
+        bench<10>("v_pk_fma x8 ONE dep chain", 8, w);
+        bench<11>("v_fma x8 TWO dep chains", 8, w);
+        bench<12>("v_pk_fma x8 TWO dep chains", 8, w);
+        bench<13>("v_fma x8 FOUR dep chains", 8, w);
+        bench<14>("v_fma clamp x8 indep", 8, w);
     }
     return 0;
 }
