@@ -287,7 +287,7 @@ __device__ __forceinline__ void rollout_pair(const KP& P, const Scenario<T>& S, 
                 // n = sqrt(c^2 + r^2 s^2), (s,c) = (sin,cos)(df)   (|df| < pi/2)
                 float sdf, cdf;
                 sincos_reduced(df_d[q], sdf, cdf);
-                const float n = rsqrtf(fmaf(ratio2 * sdf, sdf, cdf * cdf));
+                const float n = __builtin_amdgcn_rsqf(fmaf(ratio2 * sdf, sdf, cdf * cdf));   // argument in [r^2, 1]
                 cb[q] = cdf * n;
                 sb[q] = fp.lr_ratio * sdf * n;
                 const float dff = (float)df_d[q];

@@ -179,7 +179,7 @@ struct PairSink {
 // 8192 independent waves (better balance over the 2048 wave slots than 4096 double-length ones).  Each wave
 // stores its slice's best (J, c); emit_fast_kernel reduces the W partials (ties -> lowest candidate index).
 template <bool SHARED_DF, bool HI>
-__global__ __launch_bounds__(256) void search_fast_kernel(KP P, int B, int W, const float* __restrict__ x0,
+__global__ __launch_bounds__(64) void search_fast_kernel(KP P, int B, int W, const float* __restrict__ x0,
                                                           const float* __restrict__ u_prev,
                                                           const float* __restrict__ kparams,
                                                           const uint32_t* __restrict__ flags,
@@ -187,9 +187,10 @@ __global__ __launch_bounds__(256) void search_fast_kernel(KP P, int B, int W, co
                                                           const double* __restrict__ table,
                                                           const double* __restrict__ cinf,
                                                           double* __restrict__ part_J, int32_t* __restrict__ part_c) {
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int gw = blockIdx.x * 4 + wave;
-    if (gw >= B * W) return;  // wave-uniform
+    // one wave per workgroup: waves retire and are replaced independently (no intra-workgroup coupling
+    // of fast straight-route waves to slow in-arc ones)
+    const int gw = blockIdx.x;
+    if (gw >= B * W) return;
     const int b = gw / W, p = gw - b * W;
     const int lane = threadIdx.x & 63;
     Scenario<float> S;
@@ -365,7 +366,7 @@ static hipError_t launch_search_nc(const KP& P, int B, const SolveArgs<T>& A, hi
 template <bool SHARED, bool HI>
 static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>& A, hipStream_t st) {
     const int W = (P.C + 127) / 128;
-    hipLaunchKernelGGL((search_fast_kernel<SHARED, HI>), dim3(((size_t)B * W + 3) / 4), dim3(256), 0, st, P, B, W, A.x0,
+    hipLaunchKernelGGL((search_fast_kernel<SHARED, HI>), dim3((size_t)B * W), dim3(64), 0, st, P, B, W, A.x0,
                        A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.part_J, A.part_c);
     return hipGetLastError();
 }
