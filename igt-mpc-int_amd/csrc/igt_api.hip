@@ -41,8 +41,11 @@ struct igt_handle {
     bool net_set;
     void* d_stage;
     size_t stage_bytes;
-    void* d_work;          // per-slice partial arg-min workspace of the float path
+    void* d_work;          // workspace: per-slice partial arg-min, value-net records
     size_t work_bytes;
+    void* d_net;           // value-net parameters (float block followed by double block)
+    igt::DevNet<float> net_f;
+    igt::DevNet<double> net_d;
     bool prof;
     hipEvent_t ev[3];
     bool ev_recorded;
@@ -106,6 +109,20 @@ int ensure_stage(igt_handle* h, size_t bytes) {
     return 0;
 }
 
+int ensure_work(igt_handle* h, size_t bytes, hipStream_t st) {
+    if (bytes <= h->work_bytes) return 0;
+    HIPCHK(hipStreamSynchronize(st));
+    if (h->d_work) { HIPCHK(hipFree(h->d_work)); h->d_work = nullptr; h->work_bytes = 0; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    HIPCHK(hipMalloc(&h->d_work, want));
+    h->work_bytes = want;
+    return 0;
+}
+
+template <typename T> const igt::DevNet<T>& net_of(const igt_handle* h);
+template <> const igt::DevNet<float>& net_of<float>(const igt_handle* h) { return h->net_f; }
+template <> const igt::DevNet<double>& net_of<double>(const igt_handle* h) { return h->net_d; }
+
 struct Arena {   // carves 256-byte aligned pieces out of the staging buffer
     char* base;
     size_t off;
@@ -129,10 +146,10 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     const igt_params& p = h->p;
     if (p.n_obs > 0 && !obs_xy) return fail(IGT_E_INVALID, "obs_xy is null but n_obs > 0");
     if (p.cand_mode == IGT_CAND_TABLE && !h->table_set) return fail(IGT_E_STATE, "candidate table not set");
-    if (p.cost_mode == IGT_COST_VALUE_NET) {
-        if (!h->net_set) return fail(IGT_E_STATE, "value net not set");
+    const bool value = p.cost_mode == IGT_COST_VALUE_NET;
+    if (value) {
+        if (!h->net_set) return fail(IGT_E_STATE, "value net not set (igt_set_value_net)");
         if (!tv_sv || !enc) return fail(IGT_E_INVALID, "tv_sv / enc required for the value-net cost");
-        return fail(IGT_E_INVALID, "value-net cost is not available in this build");
     }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
@@ -148,13 +165,19 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
         A.tv_sv = tv_sv; A.enc = enc;
         A.x_out = x_out; A.u_out = u_out; A.cost_out = cost_out; A.argmin_out = argmin_out; A.status_out = status_out;
     } else if (mem == IGT_MEM_HOST) {
-        const size_t bytes = (n_x + n_u + n_k + n_obs + n_xo + n_uo + B) * sizeof(T) + (size_t)B * 12 + 16 * 256;
+        const size_t bytes = (n_x + 3 * n_u + n_k + n_obs + n_xo + n_uo + B) * sizeof(T) + (size_t)B * 12 + 20 * 256;
         if (int rc = ensure_stage(h, bytes)) return rc;
         Arena ar{(char*)h->d_stage, 0};
         T* dx0 = ar.take<T>(n_x); T* dup = ar.take<T>(n_u); T* dk = ar.take<T>(n_k);
         uint32_t* dfl = ar.take<uint32_t>(B); T* dob = ar.take<T>(n_obs ? n_obs : 1);
         T* dxo = ar.take<T>(n_xo); T* duo = ar.take<T>(n_uo); T* dco = ar.take<T>(B);
         int32_t* dam = ar.take<int32_t>(B); int32_t* dst = ar.take<int32_t>(B);
+        T* dtv = ar.take<T>(n_u); T* den = ar.take<T>(n_u);
+        if (value) {
+            HIPCHK(hipMemcpyAsync(dtv, tv_sv, n_u * sizeof(T), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(den, enc, n_u * sizeof(T), hipMemcpyHostToDevice, st));
+        }
+        A.tv_sv = dtv; A.enc = den;
         HIPCHK(hipMemcpyAsync(dx0, x0, n_x * sizeof(T), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(dup, u_prev, n_u * sizeof(T), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(dk, kparams, n_k * sizeof(T), hipMemcpyHostToDevice, st));
@@ -166,21 +189,34 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
         return fail(IGT_E_INVALID, "mem must be IGT_MEM_DEVICE or IGT_MEM_HOST");
     }
 
-    {   // workspace for the per-slice partial arg-min (grows on first use; never shrinks)
-        const size_t W = ((size_t)p.C + 127) / 128, need = (size_t)B * W * 12 + 256;
-        if (need > h->work_bytes) {
-            HIPCHK(hipStreamSynchronize(st));
-            if (h->d_work) { HIPCHK(hipFree(h->d_work)); h->d_work = nullptr; h->work_bytes = 0; }
-            HIPCHK(hipMalloc(&h->d_work, need + need / 4));
-            h->work_bytes = need + need / 4;
+    // workspace (grows on first use, never shrinks): per-slice partial arg-min [+ value-net records]
+    const size_t W = value ? (size_t)p.C / 64 : ((size_t)p.C + 127) / 128;
+    {
+        const size_t n_rec = value ? (size_t)B * p.C : 0;
+        const size_t need = (size_t)B * W * 12 + n_rec * (2 * sizeof(T) + 12) + (value ? (size_t)B * igt::VN_H * sizeof(T) : 0) +
+                            10 * 256;
+        if (int rc = ensure_work(h, need, st)) return rc;
+        Arena wa{(char*)h->d_work, 0};
+        A.part_J = wa.take<double>((size_t)B * W);
+        A.part_c = wa.take<int32_t>((size_t)B * W);
+        if (value) {
+            A.rec_J = wa.take<double>(n_rec);
+            A.rec_sN = wa.take<T>(n_rec);
+            A.rec_vN = wa.take<T>(n_rec);
+            A.rec_viol = wa.take<uint32_t>(n_rec);
+            A.p_vec = wa.take<T>((size_t)B * igt::VN_H);
         }
-        A.part_J = reinterpret_cast<double*>(h->d_work);
-        A.part_c = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(h->d_work) + (((size_t)B * W * 8 + 255) & ~(size_t)255));
     }
     if (h->prof) HIPCHK(hipEventRecord(h->ev[0], st));
-    HIPCHK(igt::launch_search<T>(h->kp, B, A, h->nc, st));
+    if (value) {
+        HIPCHK(igt::launch_search_records<T>(h->kp, B, A, st));
+        HIPCHK(igt::launch_value<T>(h->kp, B, net_of<T>(h), A, nullptr, nullptr, st));
+        if (sizeof(T) == 8) HIPCHK(igt::launch_reduce<T>(B, (int)W, A, st));
+    } else {
+        HIPCHK(igt::launch_search<T>(h->kp, B, A, h->nc, st));
+    }
     if (h->prof) HIPCHK(hipEventRecord(h->ev[1], st));
-    HIPCHK(igt::launch_emit<T>(h->kp, B, A, st));
+    HIPCHK(igt::launch_emit<T>(h->kp, B, (int)W, A, st));
     if (h->prof) { HIPCHK(hipEventRecord(h->ev[2], st)); h->ev_recorded = true; }
 
     if (mem == IGT_MEM_HOST) {
@@ -196,7 +232,8 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
 
 template <typename T>
 int rollout_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* kparams, const uint32_t* flags,
-                 const T* obs_xy, T* X_all, T* U_all, T* cost_all, uint32_t* viol_all, int mem, void* stream) {
+                 const T* obs_xy, const T* tv_sv, const T* enc, T* X_all, T* U_all, T* cost_all, uint32_t* viol_all,
+                 int mem, void* stream) {
     if (!h) return fail(IGT_E_INVALID, "null handle");
     if (B < 0) return fail(IGT_E_INVALID, "B < 0");
     if (B == 0) return IGT_OK;
@@ -204,7 +241,11 @@ int rollout_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T
     const igt_params& p = h->p;
     if (p.n_obs > 0 && !obs_xy) return fail(IGT_E_INVALID, "obs_xy is null but n_obs > 0");
     if (p.cand_mode == IGT_CAND_TABLE && !h->table_set) return fail(IGT_E_STATE, "candidate table not set");
-    if (p.cost_mode != IGT_COST_PROGRESS) return fail(IGT_E_INVALID, "value-net cost is not available in this build");
+    const bool value = p.cost_mode == IGT_COST_VALUE_NET;
+    if (value) {
+        if (!h->net_set) return fail(IGT_E_STATE, "value net not set (igt_set_value_net)");
+        if (!tv_sv || !enc) return fail(IGT_E_INVALID, "tv_sv / enc required for the value-net cost");
+    }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     const size_t n_x = (size_t)B * 7, n_u = (size_t)B * 2, n_k = (size_t)B * 3;
@@ -217,9 +258,10 @@ int rollout_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T
     uint32_t* dv = viol_all;
     if (mem == IGT_MEM_DEVICE) {
         A.x0 = x0; A.u_prev = u_prev; A.kparams = kparams; A.flags = flags; A.obs = obs_xy;
+        A.tv_sv = tv_sv; A.enc = enc;
     } else if (mem == IGT_MEM_HOST) {
-        const size_t bytes = (n_x + n_u + n_k + n_obs + (X_all ? n_X : 0) + (U_all ? n_U : 0) + n_c) * sizeof(T) +
-                             n_c * 4 + (size_t)B * 4 + 16 * 256;
+        const size_t bytes = (n_x + 3 * n_u + n_k + n_obs + (X_all ? n_X : 0) + (U_all ? n_U : 0) + n_c) * sizeof(T) +
+                             n_c * 4 + (size_t)B * 4 + 20 * 256;
         if (int rc = ensure_stage(h, bytes)) return rc;
         Arena ar{(char*)h->d_stage, 0};
         T* dx0 = ar.take<T>(n_x); T* dup = ar.take<T>(n_u); T* dk = ar.take<T>(n_k);
@@ -227,6 +269,12 @@ int rollout_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T
         dX = X_all ? ar.take<T>(n_X) : nullptr;
         dU = U_all ? ar.take<T>(n_U) : nullptr;
         dc = ar.take<T>(n_c); dv = ar.take<uint32_t>(n_c);
+        T* dtv = ar.take<T>(n_u); T* den = ar.take<T>(n_u);
+        if (value) {
+            HIPCHK(hipMemcpyAsync(dtv, tv_sv, n_u * sizeof(T), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(den, enc, n_u * sizeof(T), hipMemcpyHostToDevice, st));
+        }
+        A.tv_sv = dtv; A.enc = den;
         HIPCHK(hipMemcpyAsync(dx0, x0, n_x * sizeof(T), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(dup, u_prev, n_u * sizeof(T), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(dk, kparams, n_k * sizeof(T), hipMemcpyHostToDevice, st));
@@ -236,7 +284,18 @@ int rollout_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T
     } else {
         return fail(IGT_E_INVALID, "mem must be IGT_MEM_DEVICE or IGT_MEM_HOST");
     }
+    if (value) {   // records -> value_kernel fills cost_all / viol_all with the terminal term included
+        const size_t need = n_c * (2 * sizeof(T) + 12) + (size_t)B * igt::VN_H * sizeof(T) + 8 * 256;
+        if (int rc = ensure_work(h, need, st)) return rc;
+        Arena wa{(char*)h->d_work, 0};
+        A.rec_J = wa.take<double>(n_c);
+        A.rec_sN = wa.take<T>(n_c);
+        A.rec_vN = wa.take<T>(n_c);
+        A.rec_viol = wa.take<uint32_t>(n_c);
+        A.p_vec = wa.take<T>((size_t)B * igt::VN_H);
+    }
     HIPCHK(igt::launch_rollout_all<T>(h->kp, B, A, dX, dU, dc, dv, st));
+    if (value) HIPCHK(igt::launch_value<T>(h->kp, B, net_of<T>(h), A, dc, dv, st));
     if (mem == IGT_MEM_HOST) {
         if (X_all) HIPCHK(hipMemcpyAsync(X_all, dX, n_X * sizeof(T), hipMemcpyDeviceToHost, st));
         if (U_all) HIPCHK(hipMemcpyAsync(U_all, dU, n_U * sizeof(T), hipMemcpyDeviceToHost, st));
@@ -347,6 +406,7 @@ int igt_create(const igt_params* p, int device, igt_handle** out) {
     h->d_cinf = nullptr; h->d_table = nullptr; h->table_set = false; h->net_set = false;
     h->d_stage = nullptr; h->stage_bytes = 0;
     h->d_work = nullptr; h->work_bytes = 0;
+    h->d_net = nullptr;
     h->prof = false; h->ev_recorded = false;
     h->nc = 2;
     if (const char* e = std::getenv("IGT_NC")) {
@@ -372,6 +432,7 @@ int igt_destroy(igt_handle* h) {
     if (h->d_table) (void)hipFree(h->d_table);
     if (h->d_stage) (void)hipFree(h->d_stage);
     if (h->d_work) (void)hipFree(h->d_work);
+    if (h->d_net) (void)hipFree(h->d_net);
     for (int i = 0; i < 3; ++i) (void)hipEventDestroy(h->ev[i]);
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -419,9 +480,74 @@ int igt_set_candidate_table(igt_handle* h, const double* U) {
 
 int igt_set_value_net(igt_handle* h, int32_t n_layers, const int32_t* dims, const double* weights, const double* Wn,
                       const double* mu_f, double sigma_t, double mu_t) {
-    (void)n_layers; (void)dims; (void)weights; (void)Wn; (void)mu_f; (void)sigma_t; (void)mu_t;
     if (!h) return fail(IGT_E_INVALID, "null handle");
-    return fail(IGT_E_INVALID, "value-net cost is not available in this build");
+    if (!dims || !weights || !Wn || !mu_f) return fail(IGT_E_INVALID, "null argument");
+    if (n_layers != 3 && n_layers != 4) return fail(IGT_E_INVALID, "value net must have 2 or 3 hidden layers (3 or 4 Linear layers)");
+    const int H = igt::VN_H;
+    if (dims[0] != 6 || dims[n_layers] != 1) return fail(IGT_E_INVALID, "value net must map 6 -> 1");
+    for (int l = 1; l < n_layers; ++l)
+        if (dims[l] != H) return fail(IGT_E_INVALID, "hidden width must be 128");
+    const int nm = n_layers - 2;   // hidden -> hidden matrices
+    // unpack [W(out,in) row-major, b(out)] per layer
+    const double* W1 = weights;                 // [H,6]
+    const double* b1 = W1 + (size_t)H * 6;
+    const double* Wh[2] = {nullptr, nullptr};
+    const double* bh[2] = {nullptr, nullptr};
+    const double* cur = b1 + H;
+    for (int m = 0; m < nm; ++m) { Wh[m] = cur; bh[m] = cur + (size_t)H * H; cur = bh[m] + H; }
+    const double* Wo = cur;                     // [1,H]
+    const double bo = Wo[H];
+    // host block: A1[H*6] c1[H] (WT[H*H] bias[H]) x nm, wout[H]
+    const size_t n = (size_t)H * 6 + H + (size_t)nm * ((size_t)H * H + H) + H;
+    std::vector<double> blk(n);
+    double* A1 = blk.data();
+    double* c1 = A1 + (size_t)H * 6;
+    for (int i = 0; i < H; ++i) {
+        double acc = b1[i];
+        for (int k = 0; k < 6; ++k) {
+            double a = 0.0;
+            for (int j = 0; j < 6; ++j) a += W1[i * 6 + j] * Wn[j * 6 + k];     // A1 = W1 Wn
+            A1[i * 6 + k] = a;
+            acc -= a * mu_f[k];                                                 // c1 = b1 - A1 mu_f
+        }
+        c1[i] = acc;
+    }
+    double* q = c1 + H;
+    size_t offWT[2] = {0, 0}, offB[2] = {0, 0};
+    for (int m = 0; m < nm; ++m) {
+        offWT[m] = (size_t)(q - blk.data());
+        for (int i = 0; i < H; ++i)
+            for (int j = 0; j < H; ++j) q[(size_t)i * H + j] = Wh[m][(size_t)j * H + i];   // [i][j] = W[j][i]
+        q += (size_t)H * H;
+        offB[m] = (size_t)(q - blk.data());
+        for (int j = 0; j < H; ++j) q[j] = bh[m][j];
+        q += H;
+    }
+    const size_t offWo = (size_t)(q - blk.data());
+    for (int j = 0; j < H; ++j) q[j] = Wo[j];
+    std::vector<float> blkf(n);
+    for (size_t i = 0; i < n; ++i) blkf[i] = (float)blk[i];
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->d_net) { HIPCHK(hipFree(h->d_net)); h->d_net = nullptr; }
+    const size_t bytes_f = ((n * 4 + 255) / 256) * 256;
+    HIPCHK(hipMalloc(&h->d_net, bytes_f + n * 8));
+    float* df = reinterpret_cast<float*>(h->d_net);
+    double* dd = reinterpret_cast<double*>(reinterpret_cast<char*>(h->d_net) + bytes_f);
+    HIPCHK(hipMemcpy(df, blkf.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dd, blk.data(), n * 8, hipMemcpyHostToDevice));
+    auto fill = [&](auto& net, auto* base) {
+        net.A1 = base; net.c1 = base + (size_t)H * 6;
+        for (int m = 0; m < 2; ++m) { net.WT[m] = m < nm ? base + offWT[m] : nullptr; net.bias[m] = m < nm ? base + offB[m] : nullptr; }
+        net.wout = base + offWo;
+        net.n_hidden_mats = nm;
+    };
+    fill(h->net_f, df);
+    fill(h->net_d, dd);
+    h->net_f.bout = (float)bo; h->net_f.sigma_t = (float)sigma_t; h->net_f.mu_t = (float)mu_t;
+    h->net_d.bout = bo; h->net_d.sigma_t = sigma_t; h->net_d.mu_t = mu_t;
+    h->net_set = true;
+    return IGT_OK;
 }
 
 int igt_solve_batch_f32(igt_handle* h, int32_t B, const float* x0, const float* u_prev, const float* kparams,
@@ -441,14 +567,14 @@ int igt_solve_batch_f64(igt_handle* h, int32_t B, const double* x0, const double
 int igt_rollout_batch_f32(igt_handle* h, int32_t B, const float* x0, const float* u_prev, const float* kparams,
                           const uint32_t* flags, const float* obs_xy, const float* tv_sv, const float* enc,
                           float* X_all, float* U_all, float* cost_all, uint32_t* viol_all, int mem, void* stream) {
-    (void)tv_sv; (void)enc;
-    return rollout_impl<float>(h, B, x0, u_prev, kparams, flags, obs_xy, X_all, U_all, cost_all, viol_all, mem, stream);
+    return rollout_impl<float>(h, B, x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, X_all, U_all, cost_all, viol_all, mem,
+                               stream);
 }
 int igt_rollout_batch_f64(igt_handle* h, int32_t B, const double* x0, const double* u_prev, const double* kparams,
                           const uint32_t* flags, const double* obs_xy, const double* tv_sv, const double* enc,
                           double* X_all, double* U_all, double* cost_all, uint32_t* viol_all, int mem, void* stream) {
-    (void)tv_sv; (void)enc;
-    return rollout_impl<double>(h, B, x0, u_prev, kparams, flags, obs_xy, X_all, U_all, cost_all, viol_all, mem, stream);
+    return rollout_impl<double>(h, B, x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, X_all, U_all, cost_all, viol_all, mem,
+                                stream);
 }
 
 int igt_frenet_step_f32(igt_handle* h, int32_t n, const float* x, const float* u, const float* kparams, float* x_next,

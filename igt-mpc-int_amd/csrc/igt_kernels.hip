@@ -7,6 +7,7 @@
 //                   writes x*[7,N+1], u*[2,N] (1/C of the search work).
 //   rollout_all_kernel   debug/parity: every candidate's trajectory, cost and verdict bits.
 //   cartesian_euler_kernel   kinematic_bicycle_model.py:15-50, one lane per trajectory.
+#define IGT_KERNELS_TU 1
 #include "igt_device.h"
 #include "igt_fast.h"
 #include "igt_launch.h"
@@ -31,7 +32,7 @@ __device__ __forceinline__ void load_scenario(Scenario<T>& S, const KP& P, int b
 
 __device__ __forceinline__ bool finite_d(double x) { return fabs(x) < 1.79e308; }
 
-template <class Stepper, typename T, int NC, bool SHARED_DF>
+template <class Stepper, typename T, int NC, bool SHARED_DF, bool VALUE>
 __global__ __launch_bounds__(256) void search_kernel(KP P, int B, const T* __restrict__ x0,
                                                      const T* __restrict__ u_prev,
                                                      const T* __restrict__ kparams,
@@ -40,7 +41,9 @@ __global__ __launch_bounds__(256) void search_kernel(KP P, int B, const T* __res
                                                      const double* __restrict__ table,
                                                      const double* __restrict__ cinf,
                                                      T* __restrict__ cost_out, int32_t* __restrict__ argmin_out,
-                                                     int32_t* __restrict__ status_out) {
+                                                     int32_t* __restrict__ status_out, T* __restrict__ rec_sN,
+                                                     T* __restrict__ rec_vN, double* __restrict__ rec_J,
+                                                     uint32_t* __restrict__ rec_viol) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int b = blockIdx.x * 4 + wave;
     if (b >= B) return;  // wave-uniform
@@ -59,6 +62,14 @@ __global__ __launch_bounds__(256) void search_kernel(KP P, int B, const T* __res
         double J[NC], sN[NC], vN[NC];
         unsigned viol[NC];
         rollout_pass<Stepper, NC, SHARED_DF, T>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
+        if (VALUE) {   // terminal value network: leave the terminal term to value_kernel (mpc.py:369)
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const size_t idx = (size_t)b * P.C + cidx[q];
+                rec_sN[idx] = (T)sN[q]; rec_vN[idx] = (T)vN[q]; rec_J[idx] = J[q]; rec_viol[idx] = viol[q];
+            }
+            continue;
+        }
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
             const double Jq = J[q] - (sN[q] - S.x0[2]);  // mpc.py:372
@@ -75,11 +86,32 @@ __global__ __launch_bounds__(256) void search_kernel(KP P, int B, const T* __res
         const bool take = (oC >= 0) && (bestC < 0 || oJ < bestJ || (oJ == bestJ && oC < bestC));
         if (take) { bestJ = oJ; bestC = oC; }
     }
+    if (VALUE) return;
     if (lane == 0) {
         cost_out[b] = bestC >= 0 ? (T)bestJ : (T)INFINITY;
         argmin_out[b] = bestC;
         status_out[b] = bestC >= 0 ? 0 : 1;
     }
+}
+
+// partials [B, W] -> cost / argmin / status (slices ordered by candidate index: strict '<' keeps the lowest)
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_partials_kernel(int B, int W, const double* __restrict__ part_J,
+                                                              const int32_t* __restrict__ part_c,
+                                                              T* __restrict__ cost_out, int32_t* __restrict__ argmin_out,
+                                                              int32_t* __restrict__ status_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double bestJ = 0.0;
+    int c = -1;
+    for (int w = 0; w < W; ++w) {
+        const int cw = part_c[(size_t)b * W + w];
+        const double Jw = part_J[(size_t)b * W + w];
+        if (cw >= 0 && (c < 0 || Jw < bestJ)) { bestJ = Jw; c = cw; }
+    }
+    cost_out[b] = c >= 0 ? (T)bestJ : (T)INFINITY;
+    argmin_out[b] = c;
+    status_out[b] = c >= 0 ? 0 : 1;
 }
 
 template <typename T>
@@ -135,7 +167,9 @@ __global__ __launch_bounds__(256) void rollout_all_kernel(KP P, int B, const T* 
                                                           const double* __restrict__ table,
                                                           const double* __restrict__ cinf, T* __restrict__ X_all,
                                                           T* __restrict__ U_all, T* __restrict__ cost_all,
-                                                          uint32_t* __restrict__ viol_all) {
+                                                          uint32_t* __restrict__ viol_all, T* __restrict__ rec_sN,
+                                                          T* __restrict__ rec_vN, double* __restrict__ rec_J,
+                                                          uint32_t* __restrict__ rec_viol) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int b = blockIdx.x * 4 + wave;
     if (b >= B) return;
@@ -149,6 +183,10 @@ __global__ __launch_bounds__(256) void rollout_all_kernel(KP P, int B, const T* 
         double J[1], sN[1], vN[1];
         unsigned viol[1];
         rollout_pass<Stepper, 1, false, T>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
+        if (rec_J) {   // value-net cost: value_kernel adds the terminal term and fills cost_all / viol_all
+            rec_sN[bc] = (T)sN[0]; rec_vN[bc] = (T)vN[0]; rec_J[bc] = J[0]; rec_viol[bc] = viol[0];
+            continue;
+        }
         const double Jq = J[0] - (sN[0] - S.x0[2]);
         if (!finite_d(Jq)) viol[0] |= VIOL_NONFINITE;
         cost_all[bc] = (T)Jq;
@@ -178,7 +216,7 @@ struct PairSink {
 // One wave = one (scenario, 128-candidate slice): W = ceil(C/128) waves per scenario, so a B = 4096 batch is
 // 8192 independent waves (better balance over the 2048 wave slots than 4096 double-length ones).  Each wave
 // stores its slice's best (J, c); emit_fast_kernel reduces the W partials (ties -> lowest candidate index).
-template <bool SHARED_DF, bool HI>
+template <bool SHARED_DF, bool HI, bool VALUE>
 __global__ __launch_bounds__(64) void search_fast_kernel(KP P, int B, int W, const float* __restrict__ x0,
                                                           const float* __restrict__ u_prev,
                                                           const float* __restrict__ kparams,
@@ -186,7 +224,9 @@ __global__ __launch_bounds__(64) void search_fast_kernel(KP P, int B, int W, con
                                                           const float* __restrict__ obs,
                                                           const double* __restrict__ table,
                                                           const double* __restrict__ cinf,
-                                                          double* __restrict__ part_J, int32_t* __restrict__ part_c) {
+                                                          double* __restrict__ part_J, int32_t* __restrict__ part_c,
+                                                          float* __restrict__ rec_sN, float* __restrict__ rec_vN,
+                                                          double* __restrict__ rec_J, uint32_t* __restrict__ rec_viol) {
     // one wave per workgroup: waves retire and are replaced independently (no intra-workgroup coupling
     // of fast straight-route waves to slow in-arc ones)
     const int gw = blockIdx.x;
@@ -202,6 +242,14 @@ __global__ __launch_bounds__(64) void search_fast_kernel(KP P, int B, int W, con
     double J[2], sN[2], vN[2];
     unsigned viol[2];
     rollout_pair<SHARED_DF, HI, true, true, float>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
+    if (VALUE) {   // terminal value network: leave the terminal term to value_kernel (mpc.py:369)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const size_t idx = (size_t)b * P.C + cidx[q];
+            rec_sN[idx] = (float)sN[q]; rec_vN[idx] = (float)vN[q]; rec_J[idx] = J[q]; rec_viol[idx] = viol[q];
+        }
+        return;
+    }
     double bestJ = 0.0;
     int bestC = -1;
 #pragma unroll
@@ -272,7 +320,10 @@ __global__ __launch_bounds__(256) void rollout_all_fast_kernel(KP P, int B, cons
                                                                const double* __restrict__ cinf,
                                                                float* __restrict__ X_all, float* __restrict__ U_all,
                                                                float* __restrict__ cost_all,
-                                                               uint32_t* __restrict__ viol_all) {
+                                                               uint32_t* __restrict__ viol_all,
+                                                               float* __restrict__ rec_sN, float* __restrict__ rec_vN,
+                                                               double* __restrict__ rec_J,
+                                                               uint32_t* __restrict__ rec_viol) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int b = blockIdx.x * 4 + wave;
     if (b >= B) return;
@@ -289,10 +340,15 @@ __global__ __launch_bounds__(256) void rollout_all_fast_kernel(KP P, int B, cons
         rollout_pair<LATTICE, HI, true, true, float>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
+            const size_t bc = q ? bc1 : bc0;
+            if (rec_J) {   // value-net cost: value_kernel adds the terminal term and fills cost_all / viol_all
+                rec_sN[bc] = (float)sN[q]; rec_vN[bc] = (float)vN[q]; rec_J[bc] = J[q]; rec_viol[bc] = viol[q];
+                continue;
+            }
             const double Jq = J[q] - (sN[q] - S.x0[2]);
             if (!finite_d(Jq)) viol[q] |= VIOL_NONFINITE;
-            cost_all[q ? bc1 : bc0] = (float)Jq;
-            viol_all[q ? bc1 : bc0] = viol[q];
+            cost_all[bc] = (float)Jq;
+            viol_all[bc] = viol[q];
         }
     }
 }
@@ -351,54 +407,114 @@ __global__ __launch_bounds__(256) void cartesian_euler_kernel(int n, int steps, 
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
-template <class Stepper, typename T, int NC>
-static hipError_t launch_search_nc(const KP& P, int B, const SolveArgs<T>& A, hipStream_t st) {
+template <bool VALUE>
+static hipError_t launch_search_exact(const KP& P, int B, const SolveArgs<double>& A, hipStream_t st) {
+    typedef ExactStepper<double> St;
     const dim3 grid((B + 3) / 4), block(256);
     if (P.cand_mode == CAND_LATTICE)
-        hipLaunchKernelGGL((search_kernel<Stepper, T, NC, true>), grid, block, 0, st, P, B, A.x0, A.u_prev, A.kparams,
-                           A.flags, A.obs, A.table, A.cinf, A.cost_out, A.argmin_out, A.status_out);
+        hipLaunchKernelGGL((search_kernel<St, double, 1, true, VALUE>), grid, block, 0, st, P, B, A.x0, A.u_prev,
+                           A.kparams, A.flags, A.obs, A.table, A.cinf, A.cost_out, A.argmin_out, A.status_out,
+                           A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
     else
-        hipLaunchKernelGGL((search_kernel<Stepper, T, NC, false>), grid, block, 0, st, P, B, A.x0, A.u_prev, A.kparams,
-                           A.flags, A.obs, A.table, A.cinf, A.cost_out, A.argmin_out, A.status_out);
+        hipLaunchKernelGGL((search_kernel<St, double, 1, false, VALUE>), grid, block, 0, st, P, B, A.x0, A.u_prev,
+                           A.kparams, A.flags, A.obs, A.table, A.cinf, A.cost_out, A.argmin_out, A.status_out,
+                           A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
     return hipGetLastError();
 }
 
-template <bool SHARED, bool HI>
+template <bool SHARED, bool HI, bool VALUE>
 static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>& A, hipStream_t st) {
     const int W = (P.C + 127) / 128;
-    hipLaunchKernelGGL((search_fast_kernel<SHARED, HI>), dim3((size_t)B * W), dim3(64), 0, st, P, B, W, A.x0,
-                       A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.part_J, A.part_c);
+    hipLaunchKernelGGL((search_fast_kernel<SHARED, HI, VALUE>), dim3((size_t)B * W), dim3(64), 0, st, P, B, W, A.x0,
+                       A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.part_J, A.part_c, A.rec_sN, A.rec_vN,
+                       A.rec_J, A.rec_viol);
+    return hipGetLastError();
+}
+template <bool VALUE>
+static hipError_t dispatch_search_fast(const KP& P, int B, const SolveArgs<float>& A, hipStream_t st) {
+    const bool shared = P.cand_mode == CAND_LATTICE;
+    if (P.hi_order)
+        return shared ? launch_search_fast<true, true, VALUE>(P, B, A, st) : launch_search_fast<false, true, VALUE>(P, B, A, st);
+    return shared ? launch_search_fast<true, false, VALUE>(P, B, A, st) : launch_search_fast<false, false, VALUE>(P, B, A, st);
+}
+
+template <>
+hipError_t launch_search<float>(const KP& P, int B, const SolveArgs<float>& A, int, hipStream_t st) {
+    return dispatch_search_fast<false>(P, B, A, st);
+}
+template <>
+hipError_t launch_search<double>(const KP& P, int B, const SolveArgs<double>& A, int, hipStream_t st) {
+    return launch_search_exact<false>(P, B, A, st);
+}
+template <>
+hipError_t launch_search_records<float>(const KP& P, int B, const SolveArgs<float>& A, hipStream_t st) {
+    return dispatch_search_fast<true>(P, B, A, st);
+}
+template <>
+hipError_t launch_search_records<double>(const KP& P, int B, const SolveArgs<double>& A, hipStream_t st) {
+    return launch_search_exact<true>(P, B, A, st);
+}
+
+template <typename T>
+hipError_t launch_value(const KP& P, int B, const DevNet<T>& net, const SolveArgs<T>& A, T* cost_all,
+                        uint32_t* viol_all, hipStream_t st);
+template <>
+hipError_t launch_value<double>(const KP& P, int B, const DevNet<double>& net, const SolveArgs<double>& A,
+                                double* cost_all, uint32_t* viol_all, hipStream_t st) {
+    hipLaunchKernelGGL((value_prep_kernel<double>), dim3(B), dim3(VN_H), 0, st, B, net, A.tv_sv, A.enc, A.p_vec);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const size_t lds = (size_t)VN_H * 64 * sizeof(double) * (net.n_hidden_mats > 1 ? 2 : 1);
+    if (lds > 64 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_kernel<double>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((value_kernel<double>), dim3((size_t)B * (P.C / 64)), dim3(64), lds, st, B, P.C, net, A.p_vec,
+                       A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.part_J, A.part_c, cost_all, viol_all);
     return hipGetLastError();
 }
 template <>
-hipError_t launch_search<float>(const KP& P, int B, const SolveArgs<float>& A, int nc, hipStream_t st) {
-    (void)nc;
-    const bool shared = P.cand_mode == CAND_LATTICE;
-    if (P.hi_order) return shared ? launch_search_fast<true, true>(P, B, A, st) : launch_search_fast<false, true>(P, B, A, st);
-    return shared ? launch_search_fast<true, false>(P, B, A, st) : launch_search_fast<false, false>(P, B, A, st);
-}
-template <>
-hipError_t launch_search<double>(const KP& P, int B, const SolveArgs<double>& A, int nc, hipStream_t st) {
-    (void)nc;
-    return launch_search_nc<ExactStepper<double>, double, 1>(P, B, A, st);
+hipError_t launch_value<float>(const KP& P, int B, const DevNet<float>& net, const SolveArgs<float>& A, float* cost_all,
+                               uint32_t* viol_all, hipStream_t st) {
+    hipLaunchKernelGGL((value_prep_kernel<float>), dim3(B), dim3(VN_H), 0, st, B, net, A.tv_sv, A.enc, A.p_vec);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const dim3 grid((size_t)B * (P.C / 64)), block(64);
+    if (net.n_hidden_mats > 1)
+        hipLaunchKernelGGL(value_kernel_f32_h3, grid, block, 0, st, B, P.C, net, A.p_vec, A.rec_sN, A.rec_vN, A.rec_J,
+                           A.rec_viol, A.part_J, A.part_c, cost_all, viol_all);
+    else
+        hipLaunchKernelGGL(value_kernel_f32_h2, grid, block, 0, st, B, P.C, net, A.p_vec, A.rec_sN, A.rec_vN, A.rec_J,
+                           A.rec_viol, A.part_J, A.part_c, cost_all, viol_all);
+    return hipGetLastError();
 }
 
+template <typename T>
+hipError_t launch_reduce(int B, int W, const SolveArgs<T>& A, hipStream_t st) {
+    hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((B + 255) / 256), dim3(256), 0, st, B, W, A.part_J, A.part_c,
+                       A.cost_out, A.argmin_out, A.status_out);
+    return hipGetLastError();
+}
+template hipError_t launch_reduce<float>(int, int, const SolveArgs<float>&, hipStream_t);
+template hipError_t launch_reduce<double>(int, int, const SolveArgs<double>&, hipStream_t);
+
 template <bool LATTICE, bool HI>
-static hipError_t launch_emit_fast(const KP& P, int B, const SolveArgs<float>& A, hipStream_t st) {
-    const int W = (P.C + 127) / 128;
+static hipError_t launch_emit_fast(const KP& P, int B, int W, const SolveArgs<float>& A, hipStream_t st) {
     hipLaunchKernelGGL((emit_fast_kernel<LATTICE, HI>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, W, A.x0, A.u_prev,
                        A.kparams, A.flags, A.obs, A.table, A.cinf, A.part_J, A.part_c, A.cost_out, A.argmin_out,
                        A.status_out, A.x_out, A.u_out);
     return hipGetLastError();
 }
+// float path: W per-slice partials per scenario are reduced here; double path: argmin_out is already final
 template <>
-hipError_t launch_emit<float>(const KP& P, int B, const SolveArgs<float>& A, hipStream_t st) {
+hipError_t launch_emit<float>(const KP& P, int B, int W, const SolveArgs<float>& A, hipStream_t st) {
     const bool lat = P.cand_mode == CAND_LATTICE;
-    if (P.hi_order) return lat ? launch_emit_fast<true, true>(P, B, A, st) : launch_emit_fast<false, true>(P, B, A, st);
-    return lat ? launch_emit_fast<true, false>(P, B, A, st) : launch_emit_fast<false, false>(P, B, A, st);
+    if (P.hi_order) return lat ? launch_emit_fast<true, true>(P, B, W, A, st) : launch_emit_fast<false, true>(P, B, W, A, st);
+    return lat ? launch_emit_fast<true, false>(P, B, W, A, st) : launch_emit_fast<false, false>(P, B, W, A, st);
 }
 template <>
-hipError_t launch_emit<double>(const KP& P, int B, const SolveArgs<double>& A, hipStream_t st) {
+hipError_t launch_emit<double>(const KP& P, int B, int, const SolveArgs<double>& A, hipStream_t st) {
     hipLaunchKernelGGL((emit_kernel<ExactStepper<double>, double>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, A.x0,
                        A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.argmin_out, A.x_out, A.u_out);
     return hipGetLastError();
@@ -408,7 +524,8 @@ template <bool LATTICE, bool HI>
 static hipError_t launch_rollout_all_fast(const KP& P, int B, const SolveArgs<float>& A, float* X_all, float* U_all,
                                           float* cost_all, uint32_t* viol_all, hipStream_t st) {
     hipLaunchKernelGGL((rollout_all_fast_kernel<LATTICE, HI>), dim3((B + 3) / 4), dim3(256), 0, st, P, B, A.x0, A.u_prev,
-                       A.kparams, A.flags, A.obs, A.table, A.cinf, X_all, U_all, cost_all, viol_all);
+                       A.kparams, A.flags, A.obs, A.table, A.cinf, X_all, U_all, cost_all, viol_all, A.rec_sN, A.rec_vN,
+                       A.rec_J, A.rec_viol);
     return hipGetLastError();
 }
 template <>
@@ -425,7 +542,8 @@ template <>
 hipError_t launch_rollout_all<double>(const KP& P, int B, const SolveArgs<double>& A, double* X_all, double* U_all,
                                       double* cost_all, uint32_t* viol_all, hipStream_t st) {
     hipLaunchKernelGGL((rollout_all_kernel<ExactStepper<double>, double>), dim3((B + 3) / 4), dim3(256), 0, st, P, B,
-                       A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, X_all, U_all, cost_all, viol_all);
+                       A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, X_all, U_all, cost_all, viol_all,
+                       A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
     return hipGetLastError();
 }
 

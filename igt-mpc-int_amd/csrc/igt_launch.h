@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "igt_device.h"
+#include "igt_value_net.h"
 
 namespace igt {
 
@@ -22,15 +23,27 @@ struct SolveArgs {   // all device pointers
     T* cost_out;
     int32_t* argmin_out;
     int32_t* status_out;
-    double* part_J;        // [B, ceil(C/128)] per-slice best cost   (float path workspace)
-    int32_t* part_c;       // [B, ceil(C/128)] per-slice best candidate
+    double* part_J;        // [B, W] per-slice best cost        (workspace)
+    int32_t* part_c;       // [B, W] per-slice best candidate
+    // value-net cost: per-candidate records written by the search pass, consumed by value_kernel
+    T* rec_sN;             // [B, C]
+    T* rec_vN;             // [B, C]
+    double* rec_J;         // [B, C] cost without the terminal term
+    uint32_t* rec_viol;    // [B, C]
+    T* p_vec;              // [B, 128] first-layer offsets
 };
 
 template <typename T> hipError_t launch_search(const KP& P, int B, const SolveArgs<T>& A, int nc, hipStream_t st);
-template <typename T> hipError_t launch_emit(const KP& P, int B, const SolveArgs<T>& A, hipStream_t st);
+template <typename T> hipError_t launch_emit(const KP& P, int B, int W, const SolveArgs<T>& A, hipStream_t st);
+// value-net cost: search pass that writes per-candidate records, then prep + MLP + per-chunk arg-min
+template <typename T> hipError_t launch_search_records(const KP& P, int B, const SolveArgs<T>& A, hipStream_t st);
+template <typename T>
+hipError_t launch_value(const KP& P, int B, const DevNet<T>& net, const SolveArgs<T>& A, T* cost_all,
+                        uint32_t* viol_all, hipStream_t st);
+template <typename T> hipError_t launch_reduce(int B, int W, const SolveArgs<T>& A, hipStream_t st);
 template <typename T>
 hipError_t launch_rollout_all(const KP& P, int B, const SolveArgs<T>& A, T* X_all, T* U_all, T* cost_all,
-                              uint32_t* viol_all, hipStream_t st);
+                              uint32_t* viol_all, hipStream_t st);   // value mode: also fills A.rec_*
 template <typename T>
 hipError_t launch_frenet_step(const KP& P, int n, const T* x, const T* u, const T* kparams, T* x_next, hipStream_t st);
 template <typename T>

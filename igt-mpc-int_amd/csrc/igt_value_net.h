@@ -1,0 +1,258 @@
+// igt_value_net.h -- terminal value network of the gt_mpc cost (config 5).
+//
+// Reference: mpc.py:367-369  J -= V(Wn (x_N - mu_f)) * sigma_t + mu_t, with
+//   x_N = [s_tv, v_tv, e_tv, s_N - s_tv, v_N - v_tv, e_ego - e_tv]        (mpc.py:326-338)
+//   V   = Linear(6,128)-tanh-Linear(128,128)-tanh-[Linear(128,128)-tanh-]Linear(128,1)   (model.py:14-51)
+//
+// Only s_N and v_N differ between the candidates of a scenario, so the first layer is affine in two
+// scalars:  a1 = p(b) + q s_N + r v_N  with  A1 = W1 Wn,  p(b) = b1 - A1 mu_f + A1 f0(b),  q = A1[:,3],
+// r = A1[:,4]  (value_prep_kernel computes p once per scenario).  The hidden layers are evaluated per
+// candidate with one lane per candidate: activations of the lane live in its own LDS column (no
+// barriers), weights are wave-uniform and arrive through scalar loads as [i][j]-transposed rows, and 16
+// independent accumulators per lane keep the FMA stream issue-bound.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace igt {
+
+constexpr int VN_H = 128;      // hidden width of every shipped checkpoint (sc*_config.yaml: hidden_size 128)
+
+template <typename T>
+struct DevNet {                // device pointers, all wave-uniform
+    const T* A1;               // [128, 6]   W1 Wn
+    const T* c1;               // [128]      b1 - A1 mu_f
+    const T* WT[2];            // [128(i), 128(j)] transposed hidden->hidden weights
+    const T* bias[2];          // [128]
+    const T* wout;             // [128]
+    T bout, sigma_t, mu_t;
+    int n_hidden_mats;         // 1 (two hidden layers) or 2 (three hidden layers)
+};
+
+template <typename T> __device__ __forceinline__ T tanh_t(T x);
+template <> __device__ __forceinline__ float tanh_t<float>(float x) { return tanhf(x); }
+template <> __device__ __forceinline__ double tanh_t<double>(double x) { return tanh(x); }
+
+// p[b, i] = c1[i] + sum_k A1[i,k] f0[b,k],  f0 = [s_tv, v_tv, e_tv, -s_tv, -v_tv, e_ego - e_tv]
+template <typename T>
+__global__ __launch_bounds__(128) void value_prep_kernel(int B, DevNet<T> net, const T* __restrict__ tv_sv,
+                                                         const T* __restrict__ enc, T* __restrict__ p_vec) {
+    const int b = blockIdx.x, i = threadIdx.x;
+    if (b >= B) return;
+    const T s_tv = tv_sv[(size_t)b * 2 + 0], v_tv = tv_sv[(size_t)b * 2 + 1];
+    const T e_ego = enc[(size_t)b * 2 + 0], e_tv = enc[(size_t)b * 2 + 1];
+    const T f0[6] = {s_tv, v_tv, e_tv, -s_tv, -v_tv, e_ego - e_tv};
+    T acc = net.c1[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc += net.A1[i * 6 + k] * f0[k];
+    p_vec[(size_t)b * VN_H + i] = acc;
+}
+
+// one wave = 64 candidates of one scenario; one lane = one candidate.
+// Writes the chunk's best (J, c) to part_J/part_c (ties -> lowest index) and, when cost_all != nullptr
+// (rollout-all debug path), every candidate's total cost.
+template <typename T>
+__global__ __launch_bounds__(64) void value_kernel(int B, int C, DevNet<T> net, const T* __restrict__ p_vec,
+                                                   const T* __restrict__ rec_sN, const T* __restrict__ rec_vN,
+                                                   const double* __restrict__ rec_J,
+                                                   const uint32_t* __restrict__ rec_viol,
+                                                   double* __restrict__ part_J, int32_t* __restrict__ part_c,
+                                                   T* __restrict__ cost_all, uint32_t* __restrict__ viol_all) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* const hA = reinterpret_cast<T*>(smem);
+    T* const hB = hA + VN_H * 64;
+    const int chunks = C / 64;
+    const int gw = blockIdx.x;
+    if (gw >= B * chunks) return;
+    const int b = gw / chunks, chunk = gw - b * chunks;
+    const int lane = threadIdx.x;
+    const int c = chunk * 64 + lane;
+    const size_t idx = (size_t)b * C + c;
+    const T sN = rec_sN[idx], vN = rec_vN[idx];
+    const T* __restrict__ p = p_vec + (size_t)b * VN_H;
+    // layer 1 (affine in s_N, v_N) + tanh
+    for (int i = 0; i < VN_H; ++i)
+        hA[i * 64 + lane] = tanh_t<T>(p[i] + net.A1[i * 6 + 3] * sN + net.A1[i * 6 + 4] * vN);
+    // hidden -> hidden layers, 16 output neurons at a time
+    T V = net.bout;
+    for (int m = 0; m < net.n_hidden_mats; ++m) {
+        const T* __restrict__ src = (m & 1) ? hB : hA;
+        T* __restrict__ dst = (m & 1) ? hA : hB;
+        const T* __restrict__ WT = net.WT[m];
+        const T* __restrict__ bias = net.bias[m];
+        const bool last = (m == net.n_hidden_mats - 1);
+        for (int t = 0; t < VN_H / 16; ++t) {
+            T acc[16];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) acc[jj] = bias[t * 16 + jj];
+            for (int i = 0; i < VN_H; ++i) {
+                const T hv = src[i * 64 + lane];
+                const T* __restrict__ w = WT + (size_t)i * VN_H + t * 16;
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) acc[jj] += w[jj] * hv;
+            }
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const T hj = tanh_t<T>(acc[jj]);
+                if (last) V += net.wout[t * 16 + jj] * hj;
+                else dst[(t * 16 + jj) * 64 + lane] = hj;
+            }
+        }
+    }
+    // mpc.py:369: J -= V * sigma_t + mu_t
+    const double Jt = rec_J[idx] - ((double)V * (double)net.sigma_t + (double)net.mu_t);
+    unsigned viol = rec_viol[idx];
+    const bool fin = fabs(Jt) < 1.79e308;
+    if (cost_all) {
+        cost_all[idx] = (T)Jt;
+        viol_all[idx] = fin ? viol : (viol | 64u);
+    }
+    double bestJ = Jt;
+    int bestC = (viol == 0 && fin) ? c : -1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double oJ = __shfl_xor(bestJ, off, 64);
+        const int oC = __shfl_xor(bestC, off, 64);
+        const bool take = (oC >= 0) && (bestC < 0 || oJ < bestJ || (oJ == bestJ && oC < bestC));
+        if (take) { bestJ = oJ; bestC = oC; }
+    }
+    if (lane == 0 && part_J) { part_J[gw] = bestJ; part_c[gw] = bestC; }
+}
+
+// ---------------------------------------------------------------------------------------
+// float specialisation, issue-bound form: the lane's 128 activations live in VGPRs (the i-loop is fully
+// unrolled so every index is static), 16 accumulators per 16-neuron tile, weights by scalar loads that the
+// unrolled body lets the compiler keep several rows ahead; tanh = 1 - 2/(exp(2x)+1) on the hardware
+// exp2/rcp (abs error ~2e-7).  A 64-candidate chunk without a single feasible lane is skipped.
+// ---------------------------------------------------------------------------------------
+#ifdef IGT_KERNELS_TU   // non-template kernels: compiled by igt_kernels.hip only
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);        // exp(2x)
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
+
+__device__ __forceinline__ void value_finish(int gw, int c, size_t idx, float V, unsigned viol, const DevNet<float>& net,
+                                             const double* __restrict__ rec_J, double* __restrict__ part_J,
+                                             int32_t* __restrict__ part_c, float* __restrict__ cost_all,
+                                             uint32_t* __restrict__ viol_all) {
+    const double Jt = rec_J[idx] - ((double)V * (double)net.sigma_t + (double)net.mu_t);   // mpc.py:369
+    const bool fin = fabs(Jt) < 1.79e308;
+    if (cost_all) {
+        cost_all[idx] = (float)Jt;
+        viol_all[idx] = fin ? viol : (viol | 64u);
+    }
+    double bestJ = Jt;
+    int bestC = (viol == 0 && fin) ? c : -1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double oJ = __shfl_xor(bestJ, off, 64);
+        const int oC = __shfl_xor(bestC, off, 64);
+        const bool take = (oC >= 0) && (bestC < 0 || oJ < bestJ || (oJ == bestJ && oC < bestC));
+        if (take) { bestJ = oJ; bestC = oC; }
+    }
+    if ((threadIdx.x & 63) == 0 && part_J) { part_J[gw] = bestJ; part_c[gw] = bestC; }
+}
+
+// two hidden layers (one 128x128 matrix): h1[128] in VGPRs, i-loop fully unrolled
+__global__ __launch_bounds__(64) void value_kernel_f32_h2(int B, int C, DevNet<float> net, const float* __restrict__ p_vec,
+                                                          const float* __restrict__ rec_sN,
+                                                          const float* __restrict__ rec_vN,
+                                                          const double* __restrict__ rec_J,
+                                                          const uint32_t* __restrict__ rec_viol,
+                                                          double* __restrict__ part_J, int32_t* __restrict__ part_c,
+                                                          float* __restrict__ cost_all, uint32_t* __restrict__ viol_all) {
+    const int chunks = C / 64;
+    const int gw = blockIdx.x;
+    if (gw >= B * chunks) return;
+    const int b = gw / chunks, chunk = gw - b * chunks;
+    const int lane = threadIdx.x;
+    const int c = chunk * 64 + lane;
+    const size_t idx = (size_t)b * C + c;
+    const unsigned viol = rec_viol[idx];
+    if (!cost_all && !__any(viol == 0)) {                    // nothing in this chunk can win
+        if (lane == 0) { part_J[gw] = 0.0; part_c[gw] = -1; }
+        return;
+    }
+    const float sN = rec_sN[idx], vN = rec_vN[idx];
+    const float* __restrict__ p = p_vec + (size_t)b * VN_H;
+    float h[VN_H];
+#pragma unroll
+    for (int i = 0; i < VN_H; ++i)
+        h[i] = tanh_fast(fmaf(net.A1[i * 6 + 4], vN, fmaf(net.A1[i * 6 + 3], sN, p[i])));
+    float V = net.bout;
+    const float* __restrict__ WT = net.WT[0];
+    const float* __restrict__ bias = net.bias[0];
+    for (int t = 0; t < VN_H / 16; ++t) {
+        float acc[16];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) acc[jj] = bias[t * 16 + jj];
+#pragma unroll
+        for (int i = 0; i < VN_H; ++i) {
+            const float* __restrict__ w = WT + (size_t)i * VN_H + t * 16;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) acc[jj] = fmaf(w[jj], h[i], acc[jj]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) V = fmaf(net.wout[t * 16 + jj], tanh_fast(acc[jj]), V);
+    }
+    value_finish(gw, c, idx, V, viol, net, rec_J, part_J, part_c, cost_all, viol_all);
+}
+
+// three hidden layers (two 128x128 matrices), no LDS: the third layer's 128 pre-activations are the
+// register-resident accumulators; each finished h2 value is scattered into all of them at once, and h1 is
+// recomputed per 16-neuron tile (7 instructions per use) instead of being stored.
+__global__ __launch_bounds__(64) void value_kernel_f32_h3(int B, int C, DevNet<float> net, const float* __restrict__ p_vec,
+                                                          const float* __restrict__ rec_sN,
+                                                          const float* __restrict__ rec_vN,
+                                                          const double* __restrict__ rec_J,
+                                                          const uint32_t* __restrict__ rec_viol,
+                                                          double* __restrict__ part_J, int32_t* __restrict__ part_c,
+                                                          float* __restrict__ cost_all, uint32_t* __restrict__ viol_all) {
+    const int chunks = C / 64;
+    const int gw = blockIdx.x;
+    if (gw >= B * chunks) return;
+    const int b = gw / chunks, chunk = gw - b * chunks;
+    const int lane = threadIdx.x;
+    const int c = chunk * 64 + lane;
+    const size_t idx = (size_t)b * C + c;
+    const unsigned viol = rec_viol[idx];
+    if (!cost_all && !__any(viol == 0)) {
+        if (lane == 0) { part_J[gw] = 0.0; part_c[gw] = -1; }
+        return;
+    }
+    const float sN = rec_sN[idx], vN = rec_vN[idx];
+    const float* __restrict__ p = p_vec + (size_t)b * VN_H;
+    const float* __restrict__ A1 = net.A1;
+    const float* __restrict__ WT0 = net.WT[0];
+    const float* __restrict__ WT1 = net.WT[1];
+    float acc3[VN_H];
+#pragma unroll
+    for (int j = 0; j < VN_H; ++j) acc3[j] = net.bias[1][j];
+    for (int t = 0; t < VN_H / 16; ++t) {
+        float acc2[16];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) acc2[jj] = net.bias[0][t * 16 + jj];
+#pragma unroll 4
+        for (int i = 0; i < VN_H; ++i) {
+            const float h1 = tanh_fast(fmaf(A1[i * 6 + 4], vN, fmaf(A1[i * 6 + 3], sN, p[i])));
+            const float* __restrict__ w = WT0 + (size_t)i * VN_H + t * 16;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) acc2[jj] = fmaf(w[jj], h1, acc2[jj]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const float h2 = tanh_fast(acc2[jj]);
+            const float* __restrict__ w3 = WT1 + (size_t)(t * 16 + jj) * VN_H;
+#pragma unroll
+            for (int j = 0; j < VN_H; ++j) acc3[j] = fmaf(w3[j], h2, acc3[j]);
+        }
+    }
+    float V = net.bout;
+#pragma unroll
+    for (int j = 0; j < VN_H; ++j) V = fmaf(net.wout[j], tanh_fast(acc3[j]), V);
+    value_finish(gw, c, idx, V, viol, net, rec_J, part_J, part_c, cost_all, viol_all);
+}
+
+#endif  // IGT_KERNELS_TU
+
+}  // namespace igt

@@ -82,6 +82,21 @@ class BatchSolver:
             raise ValueError(f'candidate table must be [{self.C},2,{self.N}]')
         L.check(self.lib.igt_set_candidate_table(self._h, U.ctypes.data))
 
+    def set_value_net(self, layers, Wn=None, mu_f=None, sigma_t=1.0, mu_t=0.0):
+        """Terminal value network of the gt_mpc cost (mpc.py:108-127, 367-369; model.py:14-51).
+        layers = [(W[out,in], b[out]), ...] (3 or 4 Linear layers, 6 -> 128 -> ... -> 1);
+        Wn[6,6], mu_f[6]: input whitening x -> Wn (x - mu_f); sigma_t, mu_t: target de-normalisation.
+        The reference's statistics come from a dataset that is not shipped: identity by default."""
+        Wn = np.eye(6) if Wn is None else np.asarray(Wn, dtype=np.float64)
+        mu_f = np.zeros(6) if mu_f is None else np.asarray(mu_f, dtype=np.float64)
+        dims = [int(np.asarray(layers[0][0]).shape[1])] + [int(np.asarray(W).shape[0]) for W, _ in layers]
+        flat = np.concatenate([np.concatenate([np.asarray(W, np.float64).ravel(), np.asarray(b, np.float64).ravel()])
+                               for W, b in layers])
+        dims_a = np.asarray(dims, dtype=np.int32)
+        Wn_c, mu_c = np.ascontiguousarray(Wn), np.ascontiguousarray(mu_f)
+        L.check(self.lib.igt_set_value_net(self._h, len(layers), dims_a.ctypes.data, flat.ctypes.data,
+                                           Wn_c.ctypes.data, mu_c.ctypes.data, float(sigma_t), float(mu_t)))
+
     def set_profiling(self, on=True):
         L.check(self.lib.igt_set_profiling(self._h, int(on)))
 
@@ -170,7 +185,8 @@ class BatchSolver:
         L.check(self._solve(self._h, B, *ptrs, mode, self._stream_ptr(stream, mode == L.IGT_MEM_DEVICE)))
         return out
 
-    def rollout_all(self, x0, u_prev, kparams, flags, obs_xy=None, want_X=True, want_U=True, stream=None):
+    def rollout_all(self, x0, u_prev, kparams, flags, obs_xy=None, tv_sv=None, enc=None, want_X=True, want_U=True,
+                    stream=None):
         """Every candidate of every scenario (parity/debug):
         -> dict(X[B,C,7,N+1] | None, U[B,C,2,N] | None, cost[B,C], viol[B,C])."""
         B = int(x0.shape[0])
@@ -181,8 +197,8 @@ class BatchSolver:
         U = np.empty((B, Cn, 2, N), dt) if want_U else None
         cost = np.empty((B, Cn), dt)
         viol = np.empty((B, Cn), np.uint32)
-        arrs = [x0, u_prev, kparams, flags, obs_xy, None, None, X, U, cost, viol]
-        shapes = [(B, 7), (B, 2), (B, 3), (B,), (B, no, 2, N + 1), None, None,
+        arrs = [x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, X, U, cost, viol]
+        shapes = [(B, 7), (B, 2), (B, 3), (B,), (B, no, 2, N + 1), (B, 2), (B, 2),
                   (B, Cn, 7, N + 1), (B, Cn, 2, N), (B, Cn), (B, Cn)]
         dts = [dt, dt, dt, np.uint32, dt, dt, dt, dt, dt, dt, np.uint32]
         mode, ptrs, keep = self._prep(arrs, shapes, dts)

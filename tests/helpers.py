@@ -42,7 +42,8 @@ def ambiguous_mask(ref, P, eps_margin=2e-5, eps_cost=2e-5, eps_bp=2e-5, bp=None)
     near_thr = np.abs(g - P.feas_tol) < eps_margin
     amb = (contender & near_thr).any(axis=1)
     srt = np.sort(Jm, axis=1)
-    amb |= (srt[:, 1] - srt[:, 0]) < eps_cost
+    with np.errstate(invalid='ignore'):
+        amb |= (srt[:, 1] - srt[:, 0]) < eps_cost
     if bp is not None:
         amb |= (contender & (bp < eps_bp)).any(axis=1)
     return amb

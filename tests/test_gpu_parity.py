@@ -278,3 +278,58 @@ def test_full_size_properties(igt):
     bp = O.breakpoint_distance(x0, base['u'][idx].astype(np.float64), b['kparams'][idx].astype(np.float64), P)
     e = rel_err(base['x'][idx], X).max(axis=(-1, -2))
     assert e[bp > 2e-5].max() <= REL_TOL
+
+
+# ----------------------------------------------------------------------------- value network (gt_mpc, config 5)
+def _nets(golden_dir):
+    v = np.load(f'{golden_dir}/value_net_golden.npz')
+    out = {}
+    for sc in (1, 3):
+        layers, i = [], 0
+        while f'sc{sc}_W{i}' in v:
+            layers.append((v[f'sc{sc}_W{i}'], v[f'sc{sc}_b{i}']))
+            i += 1
+        out[sc] = layers
+    return out
+
+
+@pytest.mark.parametrize('sc,dtype,tol,eps', [(1, 'f64', 1e-9, 1e-9), (3, 'f64', 1e-9, 1e-9),
+                                              (1, 'f32', REL_TOL, 2e-5), (3, 'f32', REL_TOL, 2e-5)])
+def test_value_net_cost_matches_oracle(igt, golden_dir, sc, dtype, tol, eps):
+    """gt_mpc cost (mpc.py:367-369) with the shipped checkpoints V_GT_sc1 (2 hidden layers) and V_GT_sc3 (3),
+    a non-trivial whitening / de-normalisation (synthetic: the reference's statistics are not shipped)."""
+    layers = _nets(golden_dir)[sc]
+    rng = np.random.default_rng(5)
+    Wn = np.eye(6) + 0.05 * rng.normal(size=(6, 6))
+    mu_f = np.array([20.0, 2.5, 0.0, 0.0, 0.0, 0.0]) + 0.1 * rng.normal(size=6)
+    net = dict(layers=layers, Wn=Wn, mu_f=mu_f, sigma_t=3.0, mu_t=-1.5)
+    npdt = np.float64 if dtype == 'f64' else np.float32
+    b = _batch(160, npdt)
+    with igt.BatchSolver(dtype=dtype, cost_mode='value_net') as s:
+        P = oracle_params(s)
+        s.set_cinf(*_cinf())
+        with pytest.raises(igt.IgtError):
+            s.solve(*_args(b), b['tv_sv'], b['enc'])          # net not loaded yet
+        s.set_value_net(**net)
+        got = s.solve(*_args(b), b['tv_sv'], b['enc'])
+        allc = s.rollout_all(*[a[:32] for a in _args(b)], b['tv_sv'][:32], b['enc'][:32], want_X=False, want_U=False)
+    f = lambda k: np.asarray(b[k], dtype=np.float64)
+    ref = O.solve_batch(f('x0'), f('u_prev'), f('kparams'), b['flags'], f('obs_xy'), *_cinf(), P, net=net,
+                        tv_sv=f('tv_sv'), enc=f('enc'), return_all=True)
+    fin = np.isfinite(ref['J'][:32])
+    assert rel_err(allc['cost'][fin], ref['J'][:32][fin]).max() <= tol
+    kp = f('kparams')[:, None, :]
+    x0 = O.apply_flags(f('x0'), b['flags'])[:, None, :]
+    bp = O.breakpoint_distance(x0, ref['U'], kp, P)
+    amb = ambiguous_mask(ref, P, eps, eps, eps, bp)
+    ok = ~amb
+    assert ok.mean() > 0.85
+    assert (got['status'][ok] == ref['status'][ok]).all()
+    assert (got['argmin'][ok] == ref['argmin'][ok]).all()
+    sol = ok & (ref['status'] == 0)
+    assert sol.sum() > 20
+    assert rel_err(got['cost'][sol], ref['cost'][sol]).max() <= tol
+    assert rel_err(got['x'][sol], ref['x'][sol]).max() <= tol
+    # the terminal value really matters: it changes the winner w.r.t. the progress cost on this sample
+    prog = O.solve_batch(f('x0'), f('u_prev'), f('kparams'), b['flags'], f('obs_xy'), *_cinf(), P)
+    assert (prog['argmin'][sol] != ref['argmin'][sol]).any()

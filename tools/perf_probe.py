@@ -14,7 +14,7 @@ from igtmpc import BatchSolver  # noqa: E402
 from igtmpc.scenarios import make_batch  # noqa: E402
 
 
-def run(dtype, B, nc, iters=5, straight=None):
+def run(dtype, B, nc, iters=5, straight=None, net=None):
     os.environ['IGT_NC'] = str(nc)
     npdt = np.float32 if dtype == 'f32' else np.float64
     b = make_batch(B, dtype=npdt)
@@ -24,7 +24,11 @@ def run(dtype, B, nc, iters=5, straight=None):
         b['kparams'][:] = (19.3, 32.8088, 0.11627907)
     args = [torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda()
             for a in (b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy'])]
-    with BatchSolver(dtype=dtype) as s:
+    if net is not None:
+        args += [torch.from_numpy(b['tv_sv']).cuda(), torch.from_numpy(b['enc']).cuda()]
+    with BatchSolver(dtype=dtype, cost_mode='value_net' if net is not None else 'progress') as s:
+        if net is not None:
+            s.set_value_net(net)
         s.set_profiling(True)
         out = s.solve(*args)
         torch.cuda.synchronize()
@@ -39,14 +43,19 @@ def run(dtype, B, nc, iters=5, straight=None):
             te.append(e)
         st = out['status'].cpu().numpy()
     ms, me, mw = np.median(ts), np.median(te), np.median(wall) * 1e3
-    print(f'{dtype} B={B:6d} straight={straight}: search {ms:8.3f} ms  emit {me:7.3f} ms  wall {mw:8.3f} ms  '
+    print(f'{dtype} B={B:6d} straight={straight} net={None if net is None else len(net)}: search {ms:8.3f} ms  emit {me:7.3f} ms  wall {mw:8.3f} ms  '
           f'-> {B / (ms + me) * 1e3 / 1e6:7.3f} M solves/s (kernels)  feasible {np.mean(st == 0):.2f}', flush=True)
 
 
 if __name__ == '__main__':
     run('f32', 4096, 2)
     run('f32', 65536, 2)
-    run('f32', 65536, 2, straight=True)
-    run('f32', 65536, 2, straight=False)
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'value_net_golden.npz'))
+    for sc in (1, 3):
+        layers, i = [], 0
+        while f'sc{sc}_W{i}' in g:
+            layers.append((g[f'sc{sc}_W{i}'], g[f'sc{sc}_b{i}'])); i += 1
+        run('f32', 65536, 2, net=layers)
+        run('f32', 4096, 2, net=layers)
     if len(sys.argv) > 1:
         run('f64', 4096, 1, iters=2)
