@@ -43,6 +43,8 @@ struct igt_handle {
     size_t stage_bytes;
     void* d_work;          // workspace: per-slice partial arg-min, value-net records
     size_t work_bytes;
+    double* d_routes;      // [n_routes, 12] route geometry for the forecast kernel
+    int n_routes;
     void* d_net;           // value-net parameters (float block followed by double block)
     igt::DevNet<float> net_f;
     igt::DevNet<double> net_d;
@@ -338,6 +340,57 @@ int frenet_step_impl(igt_handle* h, int32_t n, const T* x, const T* u, const T* 
 }
 
 template <typename T>
+int forecast_impl(igt_handle* h, int32_t B, const T* ego_xyh, const T* opp, const T* opp_a, const int32_t* opp_route,
+                  const T* plan_x, const T* plan_u, const int32_t* has_plan, T* obs_xy, T* tv_sv, int mem, void* stream) {
+    if (!h) return fail(IGT_E_INVALID, "null handle");
+    if (B < 0) return fail(IGT_E_INVALID, "B < 0");
+    if (B == 0) return IGT_OK;
+    if (!h->d_routes) return fail(IGT_E_STATE, "route table not set (igt_set_routes)");
+    if (h->p.n_obs != 1) return fail(IGT_E_INVALID, "the forecast entry covers two-vehicle scenes (n_obs = 1)");
+    if (!ego_xyh || !opp || !opp_a || !opp_route || !obs_xy || !tv_sv) return fail(IGT_E_INVALID, "null buffer");
+    const bool plans = plan_x && plan_u && has_plan;
+    if (!plans && (plan_x || plan_u || has_plan)) return fail(IGT_E_INVALID, "plan_x, plan_u, has_plan go together");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const int N = h->p.N;
+    const size_t n_e = (size_t)B * 3, n_o = (size_t)B * 4, n_px = (size_t)B * 7 * (N + 1), n_pu = (size_t)B * 2 * N;
+    const size_t n_out = (size_t)B * 2 * (N + 1), n_tv = (size_t)B * 2;
+    const T *de = ego_xyh, *dop = opp, *da = opp_a, *dpx = plan_x, *dpu = plan_u;
+    const int32_t *dr = opp_route, *dhp = has_plan;
+    T *dout = obs_xy, *dtv = tv_sv;
+    if (mem == IGT_MEM_HOST) {
+        const size_t bytes = (n_e + n_o + B + (plans ? n_px + n_pu : 0) + n_out + n_tv) * sizeof(T) + (size_t)B * 8 + 16 * 256;
+        if (int rc = ensure_stage(h, bytes)) return rc;
+        Arena ar{(char*)h->d_stage, 0};
+        T* a0 = ar.take<T>(n_e); T* a1 = ar.take<T>(n_o); T* a2 = ar.take<T>(B);
+        int32_t* a3 = ar.take<int32_t>(B); int32_t* a4 = ar.take<int32_t>(B);
+        T* a5 = ar.take<T>(plans ? n_px : 1); T* a6 = ar.take<T>(plans ? n_pu : 1);
+        dout = ar.take<T>(n_out); dtv = ar.take<T>(n_tv);
+        HIPCHK(hipMemcpyAsync(a0, ego_xyh, n_e * sizeof(T), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(a1, opp, n_o * sizeof(T), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(a2, opp_a, (size_t)B * sizeof(T), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(a3, opp_route, (size_t)B * 4, hipMemcpyHostToDevice, st));
+        de = a0; dop = a1; da = a2; dr = a3;
+        if (plans) {
+            HIPCHK(hipMemcpyAsync(a4, has_plan, (size_t)B * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(a5, plan_x, n_px * sizeof(T), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(a6, plan_u, n_pu * sizeof(T), hipMemcpyHostToDevice, st));
+            dhp = a4; dpx = a5; dpu = a6;
+        }
+    } else if (mem != IGT_MEM_DEVICE) {
+        return fail(IGT_E_INVALID, "mem must be IGT_MEM_DEVICE or IGT_MEM_HOST");
+    }
+    HIPCHK(igt::launch_forecast<T>(h->kp, B, h->d_routes, h->n_routes, de, dop, da, dr, plans ? dpx : nullptr,
+                                   plans ? dpu : nullptr, plans ? dhp : nullptr, dout, dtv, st));
+    if (mem == IGT_MEM_HOST) {
+        HIPCHK(hipMemcpyAsync(obs_xy, dout, n_out * sizeof(T), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(tv_sv, dtv, n_tv * sizeof(T), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return IGT_OK;
+}
+
+template <typename T>
 int cartesian_impl(igt_handle* h, int32_t n, int32_t steps, const T* z0, const T* u, T* z_out, int mem, void* stream) {
     if (!h) return fail(IGT_E_INVALID, "null handle");
     if (n < 0 || steps < 0) return fail(IGT_E_INVALID, "negative size");
@@ -407,6 +460,7 @@ int igt_create(const igt_params* p, int device, igt_handle** out) {
     h->d_stage = nullptr; h->stage_bytes = 0;
     h->d_work = nullptr; h->work_bytes = 0;
     h->d_net = nullptr;
+    h->d_routes = nullptr; h->n_routes = 0;
     h->prof = false; h->ev_recorded = false;
     h->nc = 2;
     if (const char* e = std::getenv("IGT_NC")) {
@@ -433,6 +487,7 @@ int igt_destroy(igt_handle* h) {
     if (h->d_stage) (void)hipFree(h->d_stage);
     if (h->d_work) (void)hipFree(h->d_work);
     if (h->d_net) (void)hipFree(h->d_net);
+    if (h->d_routes) (void)hipFree(h->d_routes);
     for (int i = 0; i < 3; ++i) (void)hipEventDestroy(h->ev[i]);
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -584,6 +639,29 @@ int igt_frenet_step_f32(igt_handle* h, int32_t n, const float* x, const float* u
 int igt_frenet_step_f64(igt_handle* h, int32_t n, const double* x, const double* u, const double* kparams,
                         double* x_next, int mem, void* stream) {
     return frenet_step_impl<double>(h, n, x, u, kparams, x_next, mem, stream);
+}
+
+int igt_set_routes(igt_handle* h, int32_t n_routes, const double* table) {
+    if (!h || !table) return fail(IGT_E_INVALID, "null argument");
+    if (n_routes < 1 || n_routes > 64) return fail(IGT_E_INVALID, "n_routes must be in [1, 64]");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->d_routes) { HIPCHK(hipFree(h->d_routes)); h->d_routes = nullptr; h->n_routes = 0; }
+    HIPCHK(hipMalloc((void**)&h->d_routes, (size_t)n_routes * 12 * sizeof(double)));
+    HIPCHK(hipMemcpy(h->d_routes, table, (size_t)n_routes * 12 * sizeof(double), hipMemcpyHostToDevice));
+    h->n_routes = n_routes;
+    return IGT_OK;
+}
+
+int igt_forecast_batch_f32(igt_handle* h, int32_t B, const float* ego_xyh, const float* opp, const float* opp_a,
+                           const int32_t* opp_route, const float* plan_x, const float* plan_u, const int32_t* has_plan,
+                           float* obs_xy, float* tv_sv, int mem, void* stream) {
+    return forecast_impl<float>(h, B, ego_xyh, opp, opp_a, opp_route, plan_x, plan_u, has_plan, obs_xy, tv_sv, mem, stream);
+}
+int igt_forecast_batch_f64(igt_handle* h, int32_t B, const double* ego_xyh, const double* opp, const double* opp_a,
+                           const int32_t* opp_route, const double* plan_x, const double* plan_u, const int32_t* has_plan,
+                           double* obs_xy, double* tv_sv, int mem, void* stream) {
+    return forecast_impl<double>(h, B, ego_xyh, opp, opp_a, opp_route, plan_x, plan_u, has_plan, obs_xy, tv_sv, mem, stream);
 }
 
 int igt_cartesian_euler_f32(igt_handle* h, int32_t n, int32_t T, const float* z0, const float* u, float* z_out,

@@ -376,6 +376,93 @@ __global__ __launch_bounds__(256) void frenet_step_kernel(KP P, int n, const T* 
     for (int k = 0; k < 7; ++k) x_next[(size_t)i * 7 + k] = (T)o[k];
 }
 
+// ---------------------------------------------------------------------------------------
+// opponent forecast (constant_acceleration_model.py:18-82, utils.py:339-352, 365-388, 532-586)
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void frenet2global_dev(const double* __restrict__ r, T s, T& x, T& y) {
+    // r = (p0x, p0y, tx, ty, cx, cy, b0, b1, R, endx, endy, straight)
+    const T p0x = (T)r[0], p0y = (T)r[1], tx = (T)r[2], ty = (T)r[3], cx = (T)r[4], cy = (T)r[5];
+    const T b0 = (T)r[6], b1 = (T)r[7], R = (T)r[8];
+    const bool straight = r[11] != 0.0;
+    T along = s, cross = 0;
+    bool post = false;
+    if (!straight && !(s < b0)) {
+        post = s > b1;
+        const T ph = (s - b0) / R;
+        T sn, cs;
+        sincos_t<T>(ph, &sn, &cs);
+        along = b0 + R * sn;
+        cross = post ? (s - b1 + R) : R * ((T)1 - cs);
+    }
+    if (post) {   // the reference freezes the along-coordinate at the end value of its reference path
+        const T ea = (T)r[9] * (tx < 0 ? -tx : tx) + (T)r[10] * (ty < 0 ? -ty : ty);
+        const T acx = cx < 0 ? -cx : cx, acy = cy < 0 ? -cy : cy;
+        x = ea * (tx < 0 ? -tx : tx) + p0x * acx + cross * cx;
+        y = ea * (ty < 0 ? -ty : ty) + p0y * acy + cross * cy;
+    } else {
+        x = p0x + along * tx + cross * cx;
+        y = p0y + along * ty + cross * cy;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void forecast_kernel(KP P, int B, const double* __restrict__ routes, int n_routes,
+                                                       const T* __restrict__ ego_xyh, const T* __restrict__ opp,
+                                                       const T* __restrict__ opp_a,
+                                                       const int32_t* __restrict__ opp_route,
+                                                       const T* __restrict__ plan_x, const T* __restrict__ plan_u,
+                                                       const int32_t* __restrict__ has_plan, T* __restrict__ obs_xy,
+                                                       T* __restrict__ tv_sv) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int N = P.N;
+    const T dt = (T)P.dt;
+    int rid = opp_route[b];
+    rid = rid < 0 ? 0 : (rid >= n_routes ? n_routes - 1 : rid);
+    const double* __restrict__ r = routes + (size_t)rid * 12;
+    T* ox = obs_xy + (size_t)b * 2 * (N + 1);
+    T* oy = ox + (N + 1);
+    const bool shared = plan_x && has_plan && has_plan[b] != 0;
+    T x0, y0, sl, vl;
+    if (shared) {
+        // utils.py:339-352: plan states k = 1..N, then one predicted step from the plan's last state
+        const T* px = plan_x + (size_t)b * 7 * (N + 1);
+        for (int k = 0; k < N; ++k) { ox[k] = px[0 * (N + 1) + k + 1]; oy[k] = px[1 * (N + 1) + k + 1]; }
+        T s = px[2 * (N + 1) + N], v = px[5 * (N + 1) + N];
+        T a = plan_u[(size_t)b * 2 * N + (N - 1)];
+        T vn = fmin(fmax(v + a * dt, (T)-2), (T)20);                       // cam:71
+        if (vn > (T)5) { a = 0; vn = fmin(fmax(v, (T)-2), (T)20); }         // utils.py:348-349
+        s = s + (v * dt + (T)0.5 * a * dt * dt);                           // cam:70
+        T xe, ye;
+        frenet2global_dev<T>(r, s, xe, ye);
+        ox[N] = xe; oy[N] = ye;
+        sl = s; vl = vn;
+        x0 = ox[0]; y0 = oy[0];
+    } else {
+        T s = opp[(size_t)b * 4 + 2], v = opp[(size_t)b * 4 + 3];
+        const T a = opp_a[b];
+        x0 = opp[(size_t)b * 4 + 0]; y0 = opp[(size_t)b * 4 + 1];
+        ox[0] = x0; oy[0] = y0;                                            // cam:40: k = 0 is the true state
+        for (int k = 1; k <= N; ++k) {
+            s = s + (v * dt + (T)0.5 * a * dt * dt);                       // cam:70
+            v = fmin(fmax(v + a * dt, (T)-2), (T)20);                      // cam:71 (fourwayint.yaml:23-24)
+            T xk, yk;
+            frenet2global_dev<T>(r, s, xk, yk);                            // cam:75
+            ox[k] = xk; oy[k] = yk;
+        }
+        sl = s; vl = v;
+    }
+    tv_sv[(size_t)b * 2 + 0] = sl;
+    tv_sv[(size_t)b * 2 + 1] = vl;
+    // filter_preds (utils.py:365-388)
+    T sh, ch;
+    sincos_t<T>(ego_xyh[(size_t)b * 3 + 2], &sh, &ch);
+    const T dot = (x0 - ego_xyh[(size_t)b * 3 + 0]) * ch + (y0 - ego_xyh[(size_t)b * 3 + 1]) * sh;
+    if (dot < 0)
+        for (int k = 0; k <= N; ++k) { ox[k] = (T)-20; oy[k] = (T)-20; }
+}
+
 // kinematic_bicycle_model.py:27-31, T steps per trajectory
 template <typename T>
 __global__ __launch_bounds__(256) void cartesian_euler_kernel(int n, int steps, T dt, T l_r, T l_f,
@@ -561,6 +648,21 @@ hipError_t launch_frenet_step<double>(const KP& P, int n, const double* x, const
                        n, x, u, kparams, x_next);
     return hipGetLastError();
 }
+
+template <typename T>
+hipError_t launch_forecast(const KP& P, int B, const double* routes, int n_routes, const T* ego_xyh, const T* opp,
+                           const T* opp_a, const int32_t* opp_route, const T* plan_x, const T* plan_u,
+                           const int32_t* has_plan, T* obs_xy, T* tv_sv, hipStream_t st) {
+    hipLaunchKernelGGL((forecast_kernel<T>), dim3((B + 255) / 256), dim3(256), 0, st, P, B, routes, n_routes, ego_xyh, opp,
+                       opp_a, opp_route, plan_x, plan_u, has_plan, obs_xy, tv_sv);
+    return hipGetLastError();
+}
+template hipError_t launch_forecast<float>(const KP&, int, const double*, int, const float*, const float*, const float*,
+                                           const int32_t*, const float*, const float*, const int32_t*, float*, float*,
+                                           hipStream_t);
+template hipError_t launch_forecast<double>(const KP&, int, const double*, int, const double*, const double*, const double*,
+                                            const int32_t*, const double*, const double*, const int32_t*, double*, double*,
+                                            hipStream_t);
 
 template <typename T>
 hipError_t launch_cartesian(int n, int steps, double dt, double l_r, double l_f, const T* z0, const T* u, T* z_out,

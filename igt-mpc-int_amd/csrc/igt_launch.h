@@ -47,6 +47,10 @@ hipError_t launch_rollout_all(const KP& P, int B, const SolveArgs<T>& A, T* X_al
 template <typename T>
 hipError_t launch_frenet_step(const KP& P, int n, const T* x, const T* u, const T* kparams, T* x_next, hipStream_t st);
 template <typename T>
+hipError_t launch_forecast(const KP& P, int B, const double* routes, int n_routes, const T* ego_xyh, const T* opp,
+                           const T* opp_a, const int32_t* opp_route, const T* plan_x, const T* plan_u,
+                           const int32_t* has_plan, T* obs_xy, T* tv_sv, hipStream_t st);
+template <typename T>
 hipError_t launch_cartesian(int n, int steps, double dt, double l_r, double l_f, const T* z0, const T* u, T* z_out,
                             hipStream_t st);
 

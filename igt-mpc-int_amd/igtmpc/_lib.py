@@ -30,6 +30,7 @@ _SOLVE = [_vp, _i32] + [_vp] * 12 + [_i, _vp]
 _ROLL = [_vp, _i32] + [_vp] * 11 + [_i, _vp]
 _CART = [_vp, _i32, _i32, _vp, _vp, _vp, _i, _vp]
 _FSTEP = [_vp, _i32, _vp, _vp, _vp, _vp, _i, _vp]
+_FCAST = [_vp, _i32] + [_vp] * 9 + [_i, _vp]
 SYMBOLS = {
     'igt_version': (_i, []),
     'igt_last_error': (C.c_char_p, []),
@@ -44,6 +45,9 @@ SYMBOLS = {
     'igt_solve_batch_f64': (_i, _SOLVE),
     'igt_rollout_batch_f32': (_i, _ROLL),
     'igt_rollout_batch_f64': (_i, _ROLL),
+    'igt_set_routes': (_i, [_vp, _i32, _vp]),
+    'igt_forecast_batch_f32': (_i, _FCAST),
+    'igt_forecast_batch_f64': (_i, _FCAST),
     'igt_frenet_step_f32': (_i, _FSTEP),
     'igt_frenet_step_f64': (_i, _FSTEP),
     'igt_cartesian_euler_f32': (_i, _CART),

@@ -22,7 +22,6 @@ import numpy as np
 
 from . import routes as R
 from .cinf import cinf_halfplanes
-from .predictor import ConstantAccelerationModel
 from .solver import BatchSolver
 
 A_MIN_POLICY = -4.0        # mpc.yaml:8, used by the brake fallback (evaluate.py:514)
@@ -58,7 +57,6 @@ def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=
     absh = R.TABLES['abs_heading'][rid]
     flags = absh.astype(np.uint32).reshape(-1)
     u_prev = np.tile(np.array([0.1, 0.0]), (E, M, 1))                   # evaluate.py:419
-    predictor = ConstantAccelerationModel(N=N, dt=dt)                   # evaluate.py:76-77
     solver = BatchSolver(N=N, dt=dt, n_rk4=n_rk4, C=C, n_obs=M - 1, device=device, dtype=dtype, cand_mode=cand_mode)
     solver.set_cinf(*cinf_halfplanes(dt=dt, jerk=solver.params.jerk_limit))
     stepper = BatchSolver(N=1, dt=dt, n_rk4=n_rk4, C=64, n_obs=0, device=device, dtype='f64')
@@ -74,36 +72,20 @@ def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=
     sol_u = np.zeros((E, M, 2, N))
 
     for t in range(M_sim):
-        # --- predict (evaluate.py:455): constant acceleration with the previously applied a
-        pr = predictor.predict_arrays(x[..., 2].reshape(-1), x[..., 5].reshape(-1), u_prev[..., 0].reshape(-1),
-                                      rid.reshape(-1))
-        px = pr['x'].reshape(E, M, N + 1).copy()
-        py = pr['y'].reshape(E, M, N + 1).copy()
-        px[:, :, 0], py[:, :, 0] = x[..., 0], x[..., 1]                 # k = 0 is the true state (cam:40)
-        # --- V2V: agents that solved last step share their plan (utils.py:339-352)
-        if t > 0 and have_sol.any():
-            last = sol_x[:, :, :, N]                                    # last state of the shared plan
-            a_last = sol_u[:, :, 0, N - 1]
-            ext = predictor.predict_arrays(last[..., 2].reshape(-1), last[..., 5].reshape(-1), a_last.reshape(-1),
-                                           rid.reshape(-1))
-            redo = ext['v'][:, 1] > 5                                   # utils.py:348-349: retry with a = 0
-            if redo.any():
-                ext0 = predictor.predict_arrays(last[..., 2].reshape(-1), last[..., 5].reshape(-1),
-                                                np.where(redo, 0.0, a_last.reshape(-1)), rid.reshape(-1))
-                for k in ('x', 'y'):
-                    ext[k] = np.where(redo[:, None], ext0[k], ext[k])
-            sx = np.concatenate([sol_x[:, :, 0, 1:], ext['x'][:, 1].reshape(E, M, 1)], axis=2)
-            sy = np.concatenate([sol_x[:, :, 1, 1:], ext['y'][:, 1].reshape(E, M, 1)], axis=2)
-            px = np.where(have_sol[..., None], sx, px)
-            py = np.where(have_sol[..., None], sy, py)
-        # --- per ego: the other agent's forecast, filtered (utils.py:365-388)
-        obs = np.stack([px[:, ::-1], py[:, ::-1]], axis=2).reshape(E * M, 1, 2, N + 1)
-        ego_xy = np.stack([px[:, :, 0], py[:, :, 0]], axis=-1).reshape(E * M, 2)
-        obs = R.filter_preds(ego_xy, x[..., 6].reshape(-1), obs)
+        # --- forecast of the other agent for every (episode, ego) problem, on the device:
+        #     predict (evaluate.py:455) -> share motion forecasts (458-460) -> filter_preds (474)
+        other = slice(None, None, -1)
+        ego_xyh = x[:, :, [0, 1, 6]].reshape(E * M, 3)
+        opp = x[:, other][:, :, [0, 1, 2, 5]].reshape(E * M, 4)
+        obs, _tv = solver.forecast(ego_xyh.astype(npdt), opp.astype(npdt), u_prev[:, other, 0].reshape(-1).astype(npdt),
+                                   rid[:, other].reshape(-1).astype(np.int32),
+                                   sol_x[:, other].reshape(E * M, 7, N + 1).astype(npdt),
+                                   sol_u[:, other].reshape(E * M, 2, N).astype(npdt),
+                                   (have_sol[:, other] & (t > 0)).reshape(-1).astype(np.int32))
         # --- solve every (episode, agent) problem at once (evaluate.py:470-482)
         t0 = time.perf_counter()
         out = solver.solve(x.reshape(E * M, 7).astype(npdt), u_prev.reshape(E * M, 2).astype(npdt),
-                           kp.reshape(E * M, 3).astype(npdt), flags, obs.astype(npdt))
+                           kp.reshape(E * M, 3).astype(npdt), flags, obs)
         solve_ms.append((time.perf_counter() - t0) * 1e3)
         ok = (out['status'] == 0).reshape(E, M)
         xs = out['x'].reshape(E, M, 7, N + 1).astype(np.float64)

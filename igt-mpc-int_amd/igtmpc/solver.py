@@ -48,6 +48,8 @@ class BatchSolver:
         self._rollout = getattr(self.lib, f'igt_rollout_batch_{dtype}')
         self._cart = getattr(self.lib, f'igt_cartesian_euler_{dtype}')
         self._fstep = getattr(self.lib, f'igt_frenet_step_{dtype}')
+        self._fcast = getattr(self.lib, f'igt_forecast_batch_{dtype}')
+        self._routes_set = False
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -204,6 +206,39 @@ class BatchSolver:
         mode, ptrs, keep = self._prep(arrs, shapes, dts)
         L.check(self._rollout(self._h, B, *ptrs, mode, self._stream_ptr(stream, False)))
         return dict(X=X, U=U, cost=cost, viol=viol)
+
+    def set_routes(self, table=None):
+        """Route geometry for forecast(); default: the four-way intersection of igtmpc.routes."""
+        if table is None:
+            from . import routes as R
+            T = R.TABLES
+            table = np.column_stack([T['p0'], T['t'], T['c'], T['b0'], T['b1'], T['R'], T['end'],
+                                     (T['turn'] == 0).astype(np.float64)])
+        table = np.ascontiguousarray(table, dtype=np.float64)
+        if table.ndim != 2 or table.shape[1] != 12:
+            raise ValueError('route table must be [n_routes, 12]')
+        L.check(self.lib.igt_set_routes(self._h, len(table), table.ctypes.data))
+        self._routes_set = True
+
+    def forecast(self, ego_xyh, opp, opp_a, opp_route, plan_x=None, plan_u=None, has_plan=None, stream=None):
+        """Opponent forecast + V2V sharing + filter_preds on the device (constant_acceleration_model.py:18-82,
+        utils.py:339-352, 365-388): -> (obs_xy[B,1,2,N+1], tv_sv[B,2])."""
+        if not self._routes_set:
+            self.set_routes()
+        B, N = int(ego_xyh.shape[0]), self.N
+        dt = self.np_dtype
+        if _is_torch(ego_xyh):
+            import torch
+            obs = torch.empty((B, 1, 2, N + 1), dtype=ego_xyh.dtype, device=ego_xyh.device)
+            tv = torch.empty((B, 2), dtype=ego_xyh.dtype, device=ego_xyh.device)
+        else:
+            obs, tv = np.empty((B, 1, 2, N + 1), dt), np.empty((B, 2), dt)
+        arrs = [ego_xyh, opp, opp_a, opp_route, plan_x, plan_u, has_plan, obs, tv]
+        shapes = [(B, 3), (B, 4), (B,), (B,), (B, 7, N + 1), (B, 2, N), (B,), (B, 1, 2, N + 1), (B, 2)]
+        dts = [dt, dt, dt, np.int32, dt, dt, np.int32, dt, dt]
+        mode, ptrs, keep = self._prep(arrs, shapes, dts)
+        L.check(self._fcast(self._h, B, *ptrs, mode, self._stream_ptr(stream, mode == L.IGT_MEM_DEVICE)))
+        return obs, tv
 
     def frenet_step(self, x, u, kparams, stream=None):
         """One control step of the RK4 Frenet model for n states: x[n,7], u[n,2], kparams[n,3]

@@ -182,6 +182,29 @@ int igt_frenet_step_f32(igt_handle* h, int32_t n, const float* x, const float* u
 int igt_frenet_step_f64(igt_handle* h, int32_t n, const double* x, const double* u, const double* kparams,
                         double* x_next, int mem, void* stream);
 
+/* ---- opponent forecast on the device ------------------------------
+ * Route geometry for igt_forecast_batch_*: n_routes x 12 doubles per route
+ *   (p0x, p0y, tx, ty, cx, cy, b0, b1, R, endx, endy, straight)
+ * = start point of s, unit tangent, side the arc bends to, arc interval [b0,b1], radius, the frozen end
+ * coordinates the reference uses after the arc, straight flag (utils.py:532-586 frenet2global, table-driven). */
+int igt_set_routes(igt_handle* h, int32_t n_routes, const double* table);
+
+/* What each ego planner is told about its opponent at a timestep, for B problems at once.  Replaces
+ * ConstantAccelerationModel.predict (constant_acceleration_model.py:18-82), share_motion_forecasts
+ * (utils.py:339-352: an opponent that solved last step shares its plan, shifted by one step and extended by
+ * one predicted step; a = 0 if that step would exceed v = 5) and filter_preds (utils.py:365-388: an opponent
+ * behind the ego is moved to (-20,-20)).  Two-vehicle scenes (n_obs = 1).
+ *   ego_xyh  [B,3]  ego x, y, heading          opp [B,4]  opponent x, y, s, v (current)
+ *   opp_a    [B]    opponent's last applied a  opp_route [B]  route id (row of the igt_set_routes table)
+ *   plan_x [B,7,N+1], plan_u [B,2,N], has_plan [B] (int32, 0 = no shared plan)  -- all three may be NULL
+ *   obs_xy [B,1,2,N+1] (out)   tv_sv [B,2] (out): (s, v) of the last forecast state (mpc.py:330) */
+int igt_forecast_batch_f32(igt_handle* h, int32_t B, const float* ego_xyh, const float* opp, const float* opp_a,
+                           const int32_t* opp_route, const float* plan_x, const float* plan_u,
+                           const int32_t* has_plan, float* obs_xy, float* tv_sv, int mem, void* stream);
+int igt_forecast_batch_f64(igt_handle* h, int32_t B, const double* ego_xyh, const double* opp, const double* opp_a,
+                           const int32_t* opp_route, const double* plan_x, const double* plan_u,
+                           const int32_t* has_plan, double* obs_xy, double* tv_sv, int mem, void* stream);
+
 /* 4-state Cartesian forward-Euler bicycle (kinematic_bicycle_model.py:15-50), the
  * model ReferenceGen.py steps to lay out reference paths.
  *   z0 [n,4] = (x, y, psi, v)   u [n,2,T] (a, df)   z_out [n,4,T+1] */

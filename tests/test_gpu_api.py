@@ -128,3 +128,44 @@ def test_closed_loop_short_run():
     # same seed -> same episodes
     r2 = run_closed_loop(sc=3, num_samples=6, N=20, T_sim=3.0)
     assert np.array_equal(r['x_data'], r2['x_data'])
+
+
+def test_forecast_matches_oracle(golden_dir):
+    """igt_forecast_batch_* (constant-acceleration forecast, V2V plan sharing, filter_preds) against the
+    route-by-route oracle restatement; both branches (raw forecast / shared plan) and both filter outcomes."""
+    import json
+    import igtmpc
+    from igtmpc import routes as R
+    with open(f'{golden_dir}/route_constants.json') as f:
+        C = json.load(f)
+    rng = np.random.default_rng(11)
+    B, N, dt = 192, 20, 0.1
+    rid = rng.integers(0, 12, B)
+    s0 = rng.uniform(0, 50, B)
+    v0 = rng.uniform(0, 5.5, B)
+    a0 = rng.uniform(-2, 2, B)
+    xy = R.frenet2global(rid, s0)
+    opp = np.column_stack([xy, s0, v0])
+    ego = np.column_stack([rng.uniform(0, 50, B), rng.uniform(-20, 30, B), rng.uniform(-np.pi, np.pi, B)])
+    has_plan = (rng.random(B) < 0.5).astype(np.int32)
+    plan_x = rng.uniform(-5, 45, (B, 7, N + 1))
+    plan_x[:, 5, :] = rng.uniform(3.5, 5.2, (B, N + 1))              # v near the 5 m/s retry threshold
+    plan_u = rng.uniform(-1, 2, (B, 2, N))
+    for dtype, npdt, tol in (('f64', np.float64, 1e-12), ('f32', np.float32, REL_TOL)):
+        with igtmpc.BatchSolver(dtype=dtype, N=N) as s:
+            obs, tv = s.forecast(ego.astype(npdt), opp.astype(npdt), a0.astype(npdt), rid.astype(np.int32),
+                                 plan_x.astype(npdt), plan_u.astype(npdt), has_plan)
+            obs_raw, _ = s.forecast(ego.astype(npdt), opp.astype(npdt), a0.astype(npdt), rid.astype(np.int32))
+        n_filtered = 0
+        for b in range(B):
+            cast = lambda z: np.asarray(z, dtype=npdt).astype(np.float64)
+            st = [cast(opp[b, 0]), cast(opp[b, 1]), cast(opp[b, 2]), 0, 0, cast(opp[b, 3]), 0]
+            e = cast(ego[b])
+            ref, (sl, vl) = O.forecast_for_ego(R.ROUTES[rid[b]], C[R.ROUTES[rid[b]]], e[:2], e[2], st, float(cast(a0[b])), N, dt,
+                                               cast(plan_x[b]) if has_plan[b] else None, cast(plan_u[b]) if has_plan[b] else None)
+            assert rel_err(obs[b, 0], ref).max() < tol
+            assert rel_err(tv[b], [sl, vl]).max() < tol
+            ref_raw, _ = O.forecast_for_ego(R.ROUTES[rid[b]], C[R.ROUTES[rid[b]]], e[:2], e[2], st, float(cast(a0[b])), N, dt)
+            assert rel_err(obs_raw[b, 0], ref_raw).max() < tol
+            n_filtered += ref[0, 0] == -20.0
+        assert 0.2 * B < n_filtered < 0.8 * B
