@@ -114,6 +114,19 @@ struct FastPair {
         f2 s1, c1, s2, c2, v1, ey, d0, d1, acc_s, acc_ey, acc_ep, acc_x, acc_y, acc_psi;
     };
 
+    // Weighted stage sums in factorised form.  With per-stage offsets (sdA,cdA), (sdB,cdB), (sdC,cdC) of the
+    // (beta+epsi) angle and per-stage gains g_j:
+    //     sum_j w_j g_j cos(theta1 + d_j) = c1 A - s1 B,   sum_j w_j g_j sin(theta1 + d_j) = s1 A + c1 B,
+    //     A = g1 + 2 g2 cdA + 2 g3 cdB + g4 cdC,           B = 2 g2 sdA + 2 g3 sdB + g4 sdC          (w = 1,2,2,1)
+    // Both branches of substep() evaluate these through the same two helpers, so they agree bit for bit
+    // whenever K == 0 (then g_j = v_j * 1 and the offsets coincide with the psi offsets).
+    static __device__ __forceinline__ void stage_sums(f2 g1, f2 g2, f2 g3, f2 g4, f2 sdA, f2 cdA, f2 sdB, f2 cdB,
+                                                      f2 sdC, f2 cdC, f2& A, f2& B) {
+        const f2 t2 = splat(2.0f) * g2, t3 = splat(2.0f) * g3;
+        A = fma2(g4, cdC, fma2(t3, cdB, fma2(t2, cdA, g1)));
+        B = fma2(g4, sdC, fma2(t3, sdB, t2 * sdA));
+    }
+
     template <bool K0>
     __device__ __forceinline__ void substep(f2 a, f2 ha, f2 sblr, Work& w) const {
         const f2 H = splat(h), HH = splat(hh), H6 = splat(h6), BIG = splat(big), ONE = splat(1.0f), TWO = splat(2.0f);
@@ -126,66 +139,65 @@ struct FastPair {
         f2 sd2, cd2, sd3, cd3;
         ssc(HH * w1, sd2, cd2);
         ssc(HH * w2, sd3, cd3);
-        f2 ds1, ds2, ds3, ds4, de1, de2, de3, de4, dp1, dp2, dp3, dp4, sd, cd, sa, ca;
+        f2 As, Bs, Ae, Be, ip, sdC, cdC;
         if (K0) {
-            // K == 0 at every stage argument of every lane: 1 - K ey = 1, depsi = dpsi, so the
-            // (beta+epsi) stage offsets are the psi offsets.  Values are bit-identical to the
-            // general branch (it multiplies by rcp(1) = 1 and adds -ds*0).
-            ds1 = v1 * c1; de1 = v1 * s1; dp1 = w1;
-            sa = s1; ca = c1; rotate2(sa, ca, sd2, cd2);
-            ds2 = v2 * ca; de2 = v2 * sa; dp2 = w2;
-            sa = s1; ca = c1; rotate2(sa, ca, sd3, cd3);
-            ds3 = v2 * ca; de3 = v2 * sa; dp3 = w2;
-            ssc(H * w2, sd, cd);
-            sa = s1; ca = c1; rotate2(sa, ca, sd, cd);
-            ds4 = v4 * ca; de4 = v4 * sa; dp4 = w4;
+            // K == 0 at every stage argument of every lane: 1 - K ey = 1 and depsi = dpsi, so the
+            // (beta+epsi) stage offsets are the psi offsets and the gains are the speeds.
+            ssc(H * w2, sdC, cdC);
+            stage_sums(v1, v2, v2, v4, sd2, cd2, sd3, cd3, sdC, cdC, Ae, Be);
+            As = Ae; Bs = Be;
+            ip = H6 * (w1 + TWO * w2 + TWO * w2 + w4);
         } else {
             const f2 e0 = fma2(w.d0, BIG, ONE), e1 = fma2(w.d1, BIG, ONE);
             const f2 ey = w.ey;
+            f2 sdA, cdA, sdB, cdB, sa, ca;
             // ---- stage 1
             f2 K = (clamp01(e0) - clamp01(e1)) * splat(kv);
-            ds1 = v1 * c1 * rcp2(fma2(-K, ey, ONE));
-            de1 = v1 * s1;
-            dp1 = fma2(-ds1, K, w1);
+            const f2 g1 = v1 * rcp2(fma2(-K, ey, ONE));
+            const f2 ds1 = g1 * c1;
+            const f2 de1 = v1 * s1;
+            const f2 dp1 = fma2(-ds1, K, w1);
             // ---- stage 2: arguments base + h/2 k1
-            ssc(HH * dp1, sd, cd);
-            sa = s1; ca = c1; rotate2(sa, ca, sd, cd);
+            ssc(HH * dp1, sdA, cdA);
+            sa = s1; ca = c1; rotate2(sa, ca, sdA, cdA);
             K = curv(e0, e1, HH * ds1);
-            ds2 = v2 * ca * rcp2(fma2(-K, fma2(HH, de1, ey), ONE));
-            de2 = v2 * sa;
-            dp2 = fma2(-ds2, K, w2);
+            const f2 g2 = v2 * rcp2(fma2(-K, fma2(HH, de1, ey), ONE));
+            const f2 ds2 = g2 * ca;
+            const f2 de2 = v2 * sa;
+            const f2 dp2 = fma2(-ds2, K, w2);
             // ---- stage 3: base + h/2 k2
-            ssc(HH * dp2, sd, cd);
-            sa = s1; ca = c1; rotate2(sa, ca, sd, cd);
+            ssc(HH * dp2, sdB, cdB);
+            sa = s1; ca = c1; rotate2(sa, ca, sdB, cdB);
             K = curv(e0, e1, HH * ds2);
-            ds3 = v2 * ca * rcp2(fma2(-K, fma2(HH, de2, ey), ONE));
-            de3 = v2 * sa;
-            dp3 = fma2(-ds3, K, w2);
-            // ---- stage 4: base + h k3
-            ssc(H * dp3, sd, cd);
-            sa = s1; ca = c1; rotate2(sa, ca, sd, cd);
+            const f2 g3 = v2 * rcp2(fma2(-K, fma2(HH, de2, ey), ONE));
+            const f2 ds3 = g3 * ca;
+            const f2 de3 = v2 * sa;
+            const f2 dp3 = fma2(-ds3, K, w2);
+            // ---- stage 4: base + h k3 (only its cosine is needed individually, for depsi)
+            ssc(H * dp3, sdC, cdC);
             K = curv(e0, e1, H * ds3);
-            ds4 = v4 * ca * rcp2(fma2(-K, fma2(H, de3, ey), ONE));
-            de4 = v4 * sa;
-            dp4 = fma2(-ds4, K, w4);
+            const f2 g4 = v4 * rcp2(fma2(-K, fma2(H, de3, ey), ONE));
+            const f2 ds4 = g4 * fma2(c1, cdC, -(s1 * sdC));
+            const f2 dp4 = fma2(-ds4, K, w4);
+            stage_sums(g1, g2, g3, g4, sdA, cdA, sdB, cdB, sdC, cdC, As, Bs);
+            stage_sums(v1, v2, v2, v4, sdA, cdA, sdB, cdB, sdC, cdC, Ae, Be);
+            ip = H6 * (dp1 + TWO * dp2 + TWO * dp3 + dp4);
         }
-        // ---- Cartesian rows collapse to one rotation of (A,B)
+        // ---- Frenet increments (frenet.py:113-115)
+        const f2 is = H6 * fma2(c1, As, -(s1 * Bs));
+        const f2 ie = H6 * fma2(s1, Ae, c1 * Be);
+        // ---- Cartesian rows collapse to one rotation of (A,B) as well (stage 4 shares stage 3's offset)
         const f2 v34 = fma2(TWO, v2, v4);
         const f2 tv2 = TWO * v2;
-        const f2 A = fma2(v34, cd3, fma2(tv2, cd2, v1));
-        const f2 Bq = fma2(v34, sd3, tv2 * sd2);
-        const f2 dx = fma2(w.c2, A, -(w.s2 * Bq));
-        const f2 dy = fma2(w.s2, A, w.c2 * Bq);
-        // ---- combine (frenet.py:113-119)
-        const f2 is = H6 * (ds1 + TWO * ds2 + TWO * ds3 + ds4);
-        const f2 ie = H6 * (de1 + TWO * de2 + TWO * de3 + de4);
-        const f2 ip = H6 * (dp1 + TWO * dp2 + TWO * dp3 + dp4);
-        w.acc_s += is; w.acc_ey += ie; w.acc_ep += ip;
-        w.acc_x = fma2(H6, dx, w.acc_x);
-        w.acc_y = fma2(H6, dy, w.acc_y);
+        const f2 Ac = fma2(v34, cd3, fma2(tv2, cd2, v1));
+        const f2 Bc = fma2(v34, sd3, tv2 * sd2);
+        w.acc_x = fma2(H6, fma2(w.c2, Ac, -(w.s2 * Bc)), w.acc_x);
+        w.acc_y = fma2(H6, fma2(w.s2, Ac, w.c2 * Bc), w.acc_y);
         w.acc_psi = fma2(H6, w1 + splat(4.0f) * w2 + w4, w.acc_psi);
+        w.acc_s += is; w.acc_ey += ie; w.acc_ep += ip;
         w.d0 += is; w.d1 += is; w.ey += ie; w.v1 = v4;
         // ---- base pairs for the next sub-step: psi advanced by h*w2 = twice the stage-3 offset
+        f2 sd, cd;
         ssc(ip, sd, cd);
         rotate2(w.s1, w.c1, sd, cd);
         const f2 s22 = TWO * sd3 * cd3, c22 = fma2(-TWO * sd3, sd3, ONE);
