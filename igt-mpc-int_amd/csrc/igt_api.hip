@@ -70,9 +70,14 @@ int validate(const igt_params& p, std::string& why) {
     if (p.cand_mode == IGT_CAND_LATTICE) {
         const int g = isqrt_exact(p.C);
         if (g < 2 || 64 % g) { why = "lattice candidates need C = G*G with G in {2,4,8,16,32,64}; use IGT_CAND_TABLE"; return -1; }
+    } else if (p.cand_mode == IGT_CAND_RAMP_HOLD) {
+        const int g = isqrt_exact(p.C);
+        if (g < 4 || 64 % g) { why = "ramp-hold candidates need C = G*G with G in {4,8,16,32,64}"; return -1; }
     } else if (p.cand_mode != IGT_CAND_TABLE) {
         why = "unknown cand_mode"; return -1;
     }
+    if (p.refine_iters < 0 || p.refine_iters > 4) { why = "refine_iters must be in [0, 4]"; return -1; }
+    if (p.refine_iters > 0 && p.cand_mode != IGT_CAND_RAMP_HOLD) { why = "refine_iters needs IGT_CAND_RAMP_HOLD"; return -1; }
     if (p.cost_mode != IGT_COST_PROGRESS && p.cost_mode != IGT_COST_VALUE_NET) { why = "unknown cost_mode"; return -1; }
     if (!(p.v_min <= p.v_max) || !(p.a_min <= p.a_max) || !(p.df_max >= 0)) { why = "inconsistent limits"; return -1; }
     if (!(p.feas_tol >= 0)) { why = "feas_tol must be >= 0"; return -1; }
@@ -83,7 +88,8 @@ igt::KP make_kp(const igt_params& p, int F) {
     igt::KP k;
     k.N = p.N; k.n_rk4 = p.n_rk4; k.C = p.C; k.n_obs = p.n_obs;
     k.cand_mode = p.cand_mode; k.cost_mode = p.cost_mode; k.F = F;
-    k.G = p.cand_mode == IGT_CAND_LATTICE ? isqrt_exact(p.C) : 1;
+    k.G = p.cand_mode == IGT_CAND_TABLE ? 1 : isqrt_exact(p.C);
+    k.refine_it = 0;
     k.dt = p.dt;
     k.h = p.dt / p.n_rk4;                      // frenet.py:93
     k.l_r = p.l_r;
@@ -193,14 +199,17 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
 
     // workspace (grows on first use, never shrinks): per-slice partial arg-min [+ value-net records]
     const size_t W = value ? (size_t)p.C / 64 : ((size_t)p.C + 127) / 128;
+    double *d_cpar = nullptr, *d_uprev = nullptr;
     {
         const size_t n_rec = value ? (size_t)B * p.C : 0;
-        const size_t need = (size_t)B * W * 12 + n_rec * (2 * sizeof(T) + 12) + (value ? (size_t)B * igt::VN_H * sizeof(T) : 0) +
-                            10 * 256;
+        const size_t need = (size_t)B * W * 12 + (size_t)B * 48 + n_rec * (2 * sizeof(T) + 12) +
+                            (value ? (size_t)B * igt::VN_H * sizeof(T) : 0) + 12 * 256;
         if (int rc = ensure_work(h, need, st)) return rc;
         Arena wa{(char*)h->d_work, 0};
         A.part_J = wa.take<double>((size_t)B * W);
         A.part_c = wa.take<int32_t>((size_t)B * W);
+        d_cpar = wa.take<double>((size_t)B * 4);
+        d_uprev = wa.take<double>((size_t)B * 2);
         if (value) {
             A.rec_J = wa.take<double>(n_rec);
             A.rec_sN = wa.take<T>(n_rec);
@@ -210,15 +219,30 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
         }
     }
     if (h->prof) HIPCHK(hipEventRecord(h->ev[0], st));
-    if (value) {
-        HIPCHK(igt::launch_search_records<T>(h->kp, B, A, st));
-        HIPCHK(igt::launch_value<T>(h->kp, B, net_of<T>(h), A, nullptr, nullptr, st));
-        if (sizeof(T) == 8) HIPCHK(igt::launch_reduce<T>(B, (int)W, A, st));
-    } else {
-        HIPCHK(igt::launch_search<T>(h->kp, B, A, h->nc, st));
+    igt::KP kp = h->kp;
+    for (int it = 0; it <= p.refine_iters; ++it) {
+        kp.refine_it = it;
+        A.cpar = it == 0 ? nullptr : d_cpar;
+        if (value) {
+            HIPCHK(igt::launch_search_records<T>(kp, B, A, st));
+            HIPCHK(igt::launch_value<T>(kp, B, net_of<T>(h), A, nullptr, nullptr, st));
+            if (sizeof(T) == 8) HIPCHK(igt::launch_reduce<T>(B, (int)W, A, st));
+        } else {
+            HIPCHK(igt::launch_search<T>(kp, B, A, h->nc, st));
+        }
+        if (it < p.refine_iters) {   // winner of this pass -> centre / span of the next one
+            igt::SolveArgs<T> R = A;
+            int Wr = (int)W;
+            if (sizeof(T) == 8 && !value) {   // double path, progress cost: the search already reduced to one winner
+                R.part_J = reinterpret_cast<double*>(A.cost_out);
+                R.part_c = A.argmin_out;
+                Wr = 1;
+            }
+            HIPCHK(igt::launch_refine<T>(kp, B, Wr, R, d_uprev, d_cpar, it == 0 ? 1 : 0, st));
+        }
     }
     if (h->prof) HIPCHK(hipEventRecord(h->ev[1], st));
-    HIPCHK(igt::launch_emit<T>(h->kp, B, (int)W, A, st));
+    HIPCHK(igt::launch_emit<T>(kp, B, (int)W, A, st));
     if (h->prof) { HIPCHK(hipEventRecord(h->ev[2], st)); h->ev_recorded = true; }
 
     if (mem == IGT_MEM_HOST) {
@@ -440,6 +464,7 @@ int igt_params_default(igt_params* p) {
     p->d_min = 2 * 2.8;                                   /* mpc.py:45, fourwayint.yaml:9 */
     p->w_u = 0.05;                                        /* mpc.py:362 */
     p->feas_tol = 1e-6;
+    p->refine_iters = 0;
     return IGT_OK;
 }
 

@@ -19,31 +19,47 @@
 namespace igt {
 
 struct KP {  // kernel parameters (by value -> SGPRs)
-    int N, n_rk4, C, n_obs, cand_mode, cost_mode, F, G, hi_order;
+    int N, n_rk4, C, n_obs, cand_mode, cost_mode, F, G, hi_order, refine_it;
     double dt, h, l_r, lr_ratio, v_min, v_max, a_min, a_max, df_max;
     double rate_a, rate_df, ey_lim, dmin2, w_u, tol;
 };
 
-enum { CAND_LATTICE = 0, CAND_TABLE = 1 };
+enum { CAND_LATTICE = 0, CAND_TABLE = 1, CAND_RAMP_HOLD = 2 };
 enum { VIOL_BOX_V = 1, VIOL_BOX_U = 2, VIOL_RATE = 4, VIOL_EY = 8, VIOL_TERMINAL = 16,
        VIOL_COLLISION = 32, VIOL_NONFINITE = 64 };
 
 // ---------------------------------------------------------------------------------------
 // candidate control sequences (always generated in double so that u_out is the oracle's U)
 // ---------------------------------------------------------------------------------------
-struct Ctl {
-    double a, df;        // last generated control
-    double da, ddf;      // lattice increments
-};
-
 __device__ __forceinline__ double clampd(double x, double lo, double hi) {
     return fmin(fmax(x, lo), hi);
 }
 
-__device__ __forceinline__ void ctl_init(Ctl& c, const KP& P, int idx, double a_prev, double df_prev) {
+struct Ctl {
+    double a, df;        // last generated control
+    double da, ddf;      // lattice increments  /  ramp-hold: targets (a_tgt, df_tgt)
+};
+
+// Ramp-and-hold family (IGT_CAND_RAMP_HOLD): candidate (i, j) ramps a and df at the rate limits towards
+//   a_tgt = clamp(center_a + m(u_i) span_a),  df_tgt = clamp(center_df + m(u_j) span_df),  u_i = (i - G/2)/(G/2)
+// and holds them.  First pass: m(u) = u |u| sqrt|u| (dense around the centre = u_prev, span = N * rate limit);
+// refinement passes: m(u) = u around the previous winner's targets (refine_targets_kernel).
+__device__ __forceinline__ double cand_m(int i, int G, bool first) {
+    const double u = (double)(i - G / 2) / (double)(G / 2);
+    return first ? u * fabs(u) * sqrt(fabs(u)) : u;
+}
+
+
+__device__ __forceinline__ void ctl_init(Ctl& c, const KP& P, int idx, double a_prev, double df_prev,
+                                         const double (&cpar)[4]) {
     c.a = a_prev;
     c.df = df_prev;
     const int i = idx / P.G, j = idx - i * P.G;
+    if (P.cand_mode == CAND_RAMP_HOLD) {
+        c.da = clampd(cpar[0] + cand_m(i, P.G, P.refine_it == 0) * cpar[2], P.a_min, P.a_max);
+        c.ddf = clampd(cpar[1] + cand_m(j, P.G, P.refine_it == 0) * cpar[3], -P.df_max, P.df_max);
+        return;
+    }
     // da_i = -ra + (2 ra) i / (G-1)   (oracle candidates_lattice)
     c.da = -P.rate_a + (2 * P.rate_a) * (double)i / (double)(P.G - 1);
     c.ddf = -P.rate_df + (2 * P.rate_df) * (double)j / (double)(P.G - 1);
@@ -60,6 +76,9 @@ __device__ __forceinline__ unsigned ctl_step(Ctl& c, const KP& P, int idx, int k
         if (fmax(fabs(a - c.a) - P.rate_a, fabs(d - c.df) - P.rate_df) > P.tol) v |= VIOL_RATE;
         c.a = a;
         c.df = d;
+    } else if (P.cand_mode == CAND_RAMP_HOLD) {
+        c.a = clampd(c.a + clampd(c.da - c.a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
+        c.df = clampd(c.df + clampd(c.ddf - c.df, -P.rate_df, P.rate_df), -P.df_max, P.df_max);
     } else {
         c.a = clampd(c.a + c.da, P.a_min, P.a_max);
         c.df = clampd(c.df + c.ddf, -P.df_max, P.df_max);
@@ -359,6 +378,7 @@ struct Scenario {           // wave-uniform inputs of one scenario
     double x0[7];
     double a_prev, df_prev;
     double b0, b1, kv;
+    double cpar[4];         // ramp-hold candidates: centre (a, df) and span (a, df)
     const T* obs;           // [n_obs, 2, N+1]
 };
 
@@ -381,7 +401,7 @@ __device__ __forceinline__ void rollout_pass(const KP& P, const Scenario<T>& S, 
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
         stp.set(st[q], S.x0);
-        ctl_init(ctl[q], P, cidx[q], S.a_prev, S.df_prev);
+        ctl_init(ctl[q], P, cidx[q], S.a_prev, S.df_prev, S.cpar);
         bk[q].J = 0.0;
         bk[q].s0 = S.x0[2];
         bk[q].viol = 0;

@@ -233,14 +233,15 @@ struct FastPair {
 // ---------------------------------------------------------------------------------------
 // one pass over a PAIR of candidates of one scenario
 // ---------------------------------------------------------------------------------------
-// LATTICE: both candidates share the steering profile (c and c+64 have the same j) and satisfy the input
-// box / rate limits by construction; otherwise controls come from the table and are checked.
+// CAND = CAND_LATTICE / CAND_RAMP_HOLD: both candidates share the steering profile (c and c+64 have the same j)
+// and satisfy the input box / rate limits by construction; CAND_TABLE: controls come from the table and are checked.
 // BOOK = false (emit): cost and verdicts are skipped, only the trajectory is produced.
-template <bool LATTICE, bool HI_ORDER, bool BOOK, bool UNIFORM, typename T, class Sink>
+template <int CAND, bool HI_ORDER, bool BOOK, bool UNIFORM, typename T, class Sink>
 __device__ __forceinline__ void rollout_pair(const KP& P, const Scenario<T>& S, const int (&cidx)[2],
                                              const double* __restrict__ table,
                                              const double* __restrict__ cinf, Sink& sink, double (&Jout)[2],
                                              unsigned (&vout)[2], double (&sN)[2], double (&vN)[2]) {
+    constexpr bool LATTICE = CAND != CAND_TABLE;   // generated, steering shared by the pair
     typedef FastPair<HI_ORDER> FP;
     FP fp;
     fp.init(P, S.b0, S.b1, S.kv);
@@ -252,11 +253,16 @@ __device__ __forceinline__ void rollout_pair(const KP& P, const Scenario<T>& S, 
     for (int q = 0; q < 2; ++q) {
         x[q] = S.x0[0]; y[q] = S.x0[1]; s[q] = S.x0[2]; ey[q] = S.x0[3]; ep[q] = S.x0[4]; v[q] = S.x0[5]; psi[q] = S.x0[6];
         a_d[q] = S.a_prev; df_d[q] = S.df_prev;
-        if (LATTICE) {
+        if (CAND == CAND_LATTICE) {
             // da_i = -ra + (2 ra) i/(G-1), ddf_j likewise (oracle candidates_lattice)
             const int i = cidx[q] / P.G, j = cidx[q] - i * P.G;
             da[q] = -P.rate_a + (2 * P.rate_a) * (double)i / (double)(P.G - 1);
             if (q == 0) ddf = -P.rate_df + (2 * P.rate_df) * (double)j / (double)(P.G - 1);
+        } else if (CAND == CAND_RAMP_HOLD) {
+            // da / ddf hold the TARGETS here (igt_device.h cand_m)
+            const int i = cidx[q] / P.G, j = cidx[q] - i * P.G;
+            da[q] = clampd(S.cpar[0] + cand_m(i, P.G, P.refine_it == 0) * S.cpar[2], P.a_min, P.a_max);
+            if (q == 0) ddf = clampd(S.cpar[1] + cand_m(j, P.G, P.refine_it == 0) * S.cpar[3], -P.df_max, P.df_max);
         }
         J[q] = 0.0; viol[q] = 0;
         sink.state(q, 0, S.x0);
@@ -271,11 +277,16 @@ __device__ __forceinline__ void rollout_pair(const KP& P, const Scenario<T>& S, 
     for (int k = 0; k < P.N; ++k) {
         // ---- controls of step k (double)
         f2 a, cb, sb, tu;
-        if (LATTICE) {
+        if (CAND == CAND_LATTICE) {
             df_d[0] = clampd(df_d[0] + ddf, -P.df_max, P.df_max);
             df_d[1] = df_d[0];
             a_d[0] = clampd(a_d[0] + da[0], P.a_min, P.a_max);
             a_d[1] = clampd(a_d[1] + da[1], P.a_min, P.a_max);
+        } else if (CAND == CAND_RAMP_HOLD) {
+            df_d[0] = clampd(df_d[0] + clampd(ddf - df_d[0], -P.rate_df, P.rate_df), -P.df_max, P.df_max);
+            df_d[1] = df_d[0];
+            a_d[0] = clampd(a_d[0] + clampd(da[0] - a_d[0], -P.rate_a, P.rate_a), P.a_min, P.a_max);
+            a_d[1] = clampd(a_d[1] + clampd(da[1] - a_d[1], -P.rate_a, P.rate_a), P.a_min, P.a_max);
         } else {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {

@@ -17,7 +17,8 @@ namespace igt {
 template <typename T>
 __device__ __forceinline__ void load_scenario(Scenario<T>& S, const KP& P, int b, const T* __restrict__ x0,
                                               const T* __restrict__ u_prev, const T* __restrict__ kparams,
-                                              const uint32_t* __restrict__ flags, const T* __restrict__ obs) {
+                                              const uint32_t* __restrict__ flags, const T* __restrict__ obs,
+                                              const double* __restrict__ cpar = nullptr) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) S.x0[i] = (double)x0[(size_t)b * 7 + i];
     // ego routes '32','41' use |heading| (mpc.py:231-234, 282-285)
@@ -28,6 +29,13 @@ __device__ __forceinline__ void load_scenario(Scenario<T>& S, const KP& P, int b
     S.b1 = (double)kparams[(size_t)b * 3 + 1];
     S.kv = (double)kparams[(size_t)b * 3 + 2];
     S.obs = obs + (size_t)b * P.n_obs * 2 * (P.N + 1);
+    if (cpar) {          // ramp-hold refinement pass: centre / span chosen by refine_targets_kernel
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S.cpar[i] = cpar[(size_t)b * 4 + i];
+    } else {             // first pass: centre = u_prev, span = what the rate limits reach over the horizon
+        S.cpar[0] = S.a_prev; S.cpar[1] = S.df_prev;
+        S.cpar[2] = P.N * P.rate_a; S.cpar[3] = P.N * P.rate_df;
+    }
 }
 
 __device__ __forceinline__ bool finite_d(double x) { return fabs(x) < 1.79e308; }
@@ -39,7 +47,7 @@ __global__ __launch_bounds__(256) void search_kernel(KP P, int B, const T* __res
                                                      const uint32_t* __restrict__ flags,
                                                      const T* __restrict__ obs,
                                                      const double* __restrict__ table,
-                                                     const double* __restrict__ cinf,
+                                                     const double* __restrict__ cinf, const double* __restrict__ cpar,
                                                      T* __restrict__ cost_out, int32_t* __restrict__ argmin_out,
                                                      int32_t* __restrict__ status_out, T* __restrict__ rec_sN,
                                                      T* __restrict__ rec_vN, double* __restrict__ rec_J,
@@ -49,7 +57,7 @@ __global__ __launch_bounds__(256) void search_kernel(KP P, int B, const T* __res
     if (b >= B) return;  // wave-uniform
     const int lane = threadIdx.x & 63;
     Scenario<T> S;
-    load_scenario<T>(S, P, b, x0, u_prev, kparams, flags, obs);
+    load_scenario<T>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
 
     double bestJ = 0.0;
     int bestC = -1;
@@ -114,6 +122,48 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(int B, int W, cons
     status_out[b] = c >= 0 ? 0 : 1;
 }
 
+// Ramp-hold refinement: new candidate centre = the winner's targets, new span = half the distance between
+// the winner's neighbours on the previous grid.  No feasible candidate: parameters are left as they are.
+__global__ __launch_bounds__(256) void refine_targets_kernel(KP P, int B, int W, const double* __restrict__ part_J,
+                                                             const int32_t* __restrict__ part_c,
+                                                             const double* __restrict__ u_prev_d,
+                                                             double* __restrict__ cpar, int first) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double ca, cd, sa, sd;
+    if (first) {   // parameters of the first pass (load_scenario's defaults)
+        ca = u_prev_d[(size_t)b * 2 + 0]; cd = u_prev_d[(size_t)b * 2 + 1];
+        sa = P.N * P.rate_a; sd = P.N * P.rate_df;
+    } else {
+        ca = cpar[(size_t)b * 4 + 0]; cd = cpar[(size_t)b * 4 + 1]; sa = cpar[(size_t)b * 4 + 2]; sd = cpar[(size_t)b * 4 + 3];
+    }
+    double bestJ = 0.0;
+    int c = -1;
+    for (int w = 0; w < W; ++w) {
+        const int cw = part_c[(size_t)b * W + w];
+        const double Jw = part_J[(size_t)b * W + w];
+        if (cw >= 0 && (c < 0 || Jw < bestJ)) { bestJ = Jw; c = cw; }
+    }
+    if (c >= 0) {
+        const int G = P.G, i = c / G, j = c - i * G;
+        const int ilo = i > 0 ? i - 1 : i, ihi = i < G - 1 ? i + 1 : i;
+        const int jlo = j > 0 ? j - 1 : j, jhi = j < G - 1 ? j + 1 : j;
+        const bool f = first != 0;
+        const double na = clampd(ca + cand_m(i, G, f) * sa, P.a_min, P.a_max);
+        const double nd = clampd(cd + cand_m(j, G, f) * sd, -P.df_max, P.df_max);
+        sa = sa * (cand_m(ihi, G, f) - cand_m(ilo, G, f)) / (double)(ihi - ilo > 1 ? 2 : 1);
+        sd = sd * (cand_m(jhi, G, f) - cand_m(jlo, G, f)) / (double)(jhi - jlo > 1 ? 2 : 1);
+        ca = na; cd = nd;
+    }
+    cpar[(size_t)b * 4 + 0] = ca; cpar[(size_t)b * 4 + 1] = cd; cpar[(size_t)b * 4 + 2] = sa; cpar[(size_t)b * 4 + 3] = sd;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void to_double_kernel(size_t n, const T* __restrict__ in, double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
+}
+
 template <typename T>
 struct StoreSink {
     T* x;   // [7, N+1] of this scenario/candidate (may be null)
@@ -135,7 +185,7 @@ __global__ __launch_bounds__(64) void emit_kernel(KP P, int B, const T* __restri
                                                   const T* __restrict__ u_prev, const T* __restrict__ kparams,
                                                   const uint32_t* __restrict__ flags, const T* __restrict__ obs,
                                                   const double* __restrict__ table,
-                                                  const double* __restrict__ cinf,
+                                                  const double* __restrict__ cinf, const double* __restrict__ cpar,
                                                   const int32_t* __restrict__ argmin, T* __restrict__ x_out,
                                                   T* __restrict__ u_out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -150,7 +200,7 @@ __global__ __launch_bounds__(64) void emit_kernel(KP P, int B, const T* __restri
         return;
     }
     Scenario<T> S;
-    load_scenario<T>(S, P, b, x0, u_prev, kparams, flags, obs);
+    load_scenario<T>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
     StoreSink<T> sink{xo, uo, P.N};
     const int cidx[1] = {c};
     double J[1], sN[1], vN[1];
@@ -165,7 +215,7 @@ __global__ __launch_bounds__(256) void rollout_all_kernel(KP P, int B, const T* 
                                                           const uint32_t* __restrict__ flags,
                                                           const T* __restrict__ obs,
                                                           const double* __restrict__ table,
-                                                          const double* __restrict__ cinf, T* __restrict__ X_all,
+                                                          const double* __restrict__ cinf, const double* __restrict__ cpar, T* __restrict__ X_all,
                                                           T* __restrict__ U_all, T* __restrict__ cost_all,
                                                           uint32_t* __restrict__ viol_all, T* __restrict__ rec_sN,
                                                           T* __restrict__ rec_vN, double* __restrict__ rec_J,
@@ -175,7 +225,7 @@ __global__ __launch_bounds__(256) void rollout_all_kernel(KP P, int B, const T* 
     if (b >= B) return;
     const int lane = threadIdx.x & 63;
     Scenario<T> S;
-    load_scenario<T>(S, P, b, x0, u_prev, kparams, flags, obs);
+    load_scenario<T>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
     for (int c = lane; c < P.C; c += 64) {
         const size_t bc = (size_t)b * P.C + c;
         StoreSink<T> sink{X_all ? X_all + bc * 7 * (P.N + 1) : nullptr, U_all ? U_all + bc * 2 * P.N : nullptr, P.N};
@@ -216,14 +266,14 @@ struct PairSink {
 // One wave = one (scenario, 128-candidate slice): W = ceil(C/128) waves per scenario, so a B = 4096 batch is
 // 8192 independent waves (better balance over the 2048 wave slots than 4096 double-length ones).  Each wave
 // stores its slice's best (J, c); emit_fast_kernel reduces the W partials (ties -> lowest candidate index).
-template <bool SHARED_DF, bool HI, bool VALUE>
+template <int CAND, bool HI, bool VALUE>
 __global__ __launch_bounds__(64) void search_fast_kernel(KP P, int B, int W, const float* __restrict__ x0,
                                                           const float* __restrict__ u_prev,
                                                           const float* __restrict__ kparams,
                                                           const uint32_t* __restrict__ flags,
                                                           const float* __restrict__ obs,
                                                           const double* __restrict__ table,
-                                                          const double* __restrict__ cinf,
+                                                          const double* __restrict__ cinf, const double* __restrict__ cpar,
                                                           double* __restrict__ part_J, int32_t* __restrict__ part_c,
                                                           float* __restrict__ rec_sN, float* __restrict__ rec_vN,
                                                           double* __restrict__ rec_J, uint32_t* __restrict__ rec_viol) {
@@ -234,14 +284,14 @@ __global__ __launch_bounds__(64) void search_fast_kernel(KP P, int B, int W, con
     const int b = gw / W, p = gw - b * W;
     const int lane = threadIdx.x & 63;
     Scenario<float> S;
-    load_scenario<float>(S, P, b, x0, u_prev, kparams, flags, obs);
+    load_scenario<float>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
     NullSink sink;
     const int chunks = P.C / 64;
     // an odd number of 64-candidate chunks: the last slice rolls its chunk twice (harmless duplicate)
     const int cidx[2] = {(2 * p) * 64 + lane, (2 * p + 1 < chunks ? 2 * p + 1 : 2 * p) * 64 + lane};
     double J[2], sN[2], vN[2];
     unsigned viol[2];
-    rollout_pair<SHARED_DF, HI, true, true, float>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
+    rollout_pair<CAND, HI, true, true, float>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
     if (VALUE) {   // terminal value network: leave the terminal term to value_kernel (mpc.py:369)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -268,14 +318,14 @@ __global__ __launch_bounds__(64) void search_fast_kernel(KP P, int B, int W, con
     if (lane == 0) { part_J[gw] = bestJ; part_c[gw] = bestC; }
 }
 
-template <bool LATTICE, bool HI>
+template <int CAND, bool HI>
 __global__ __launch_bounds__(64) void emit_fast_kernel(KP P, int B, int W, const float* __restrict__ x0,
                                                        const float* __restrict__ u_prev,
                                                        const float* __restrict__ kparams,
                                                        const uint32_t* __restrict__ flags,
                                                        const float* __restrict__ obs,
                                                        const double* __restrict__ table,
-                                                       const double* __restrict__ cinf,
+                                                       const double* __restrict__ cinf, const double* __restrict__ cpar,
                                                        const double* __restrict__ part_J,
                                                        const int32_t* __restrict__ part_c,
                                                        float* __restrict__ cost_out, int32_t* __restrict__ argmin_out,
@@ -302,22 +352,22 @@ __global__ __launch_bounds__(64) void emit_fast_kernel(KP P, int B, int W, const
         return;
     }
     Scenario<float> S;
-    load_scenario<float>(S, P, b, x0, u_prev, kparams, flags, obs);
+    load_scenario<float>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
     PairSink<float> sink{{xo, nullptr}, {uo, nullptr}, P.N};
     const int cidx[2] = {c, c};
     double J[2], sN[2], vN[2];
     unsigned viol[2];
-    rollout_pair<LATTICE, HI, false, false, float>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
+    rollout_pair<CAND, HI, false, false, float>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
 }
 
-template <bool LATTICE, bool HI>
+template <int CAND, bool HI>
 __global__ __launch_bounds__(256) void rollout_all_fast_kernel(KP P, int B, const float* __restrict__ x0,
                                                                const float* __restrict__ u_prev,
                                                                const float* __restrict__ kparams,
                                                                const uint32_t* __restrict__ flags,
                                                                const float* __restrict__ obs,
                                                                const double* __restrict__ table,
-                                                               const double* __restrict__ cinf,
+                                                               const double* __restrict__ cinf, const double* __restrict__ cpar,
                                                                float* __restrict__ X_all, float* __restrict__ U_all,
                                                                float* __restrict__ cost_all,
                                                                uint32_t* __restrict__ viol_all,
@@ -329,7 +379,7 @@ __global__ __launch_bounds__(256) void rollout_all_fast_kernel(KP P, int B, cons
     if (b >= B) return;
     const int lane = threadIdx.x & 63;
     Scenario<float> S;
-    load_scenario<float>(S, P, b, x0, u_prev, kparams, flags, obs);
+    load_scenario<float>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
     for (int c = lane; c < P.C; c += 128) {
         const int cidx[2] = {c, c + 64 < P.C ? c + 64 : c};
         const size_t bc0 = (size_t)b * P.C + c, bc1 = (size_t)b * P.C + cidx[1];
@@ -337,7 +387,7 @@ __global__ __launch_bounds__(256) void rollout_all_fast_kernel(KP P, int B, cons
                              {U_all ? U_all + bc0 * 2 * P.N : nullptr, U_all ? U_all + bc1 * 2 * P.N : nullptr}, P.N};
         double J[2], sN[2], vN[2];
         unsigned viol[2];
-        rollout_pair<LATTICE, HI, true, true, float>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
+        rollout_pair<CAND, HI, true, true, float>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const size_t bc = q ? bc1 : bc0;
@@ -498,31 +548,35 @@ template <bool VALUE>
 static hipError_t launch_search_exact(const KP& P, int B, const SolveArgs<double>& A, hipStream_t st) {
     typedef ExactStepper<double> St;
     const dim3 grid((B + 3) / 4), block(256);
-    if (P.cand_mode == CAND_LATTICE)
+    if (P.cand_mode != CAND_TABLE)
         hipLaunchKernelGGL((search_kernel<St, double, 1, true, VALUE>), grid, block, 0, st, P, B, A.x0, A.u_prev,
-                           A.kparams, A.flags, A.obs, A.table, A.cinf, A.cost_out, A.argmin_out, A.status_out,
+                           A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.cost_out, A.argmin_out, A.status_out,
                            A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
     else
         hipLaunchKernelGGL((search_kernel<St, double, 1, false, VALUE>), grid, block, 0, st, P, B, A.x0, A.u_prev,
-                           A.kparams, A.flags, A.obs, A.table, A.cinf, A.cost_out, A.argmin_out, A.status_out,
+                           A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.cost_out, A.argmin_out, A.status_out,
                            A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
     return hipGetLastError();
 }
 
-template <bool SHARED, bool HI, bool VALUE>
+template <int CAND, bool HI, bool VALUE>
 static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>& A, hipStream_t st) {
     const int W = (P.C + 127) / 128;
-    hipLaunchKernelGGL((search_fast_kernel<SHARED, HI, VALUE>), dim3((size_t)B * W), dim3(64), 0, st, P, B, W, A.x0,
-                       A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.part_J, A.part_c, A.rec_sN, A.rec_vN,
+    hipLaunchKernelGGL((search_fast_kernel<CAND, HI, VALUE>), dim3((size_t)B * W), dim3(64), 0, st, P, B, W, A.x0,
+                       A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN, A.rec_vN,
                        A.rec_J, A.rec_viol);
     return hipGetLastError();
 }
 template <bool VALUE>
 static hipError_t dispatch_search_fast(const KP& P, int B, const SolveArgs<float>& A, hipStream_t st) {
-    const bool shared = P.cand_mode == CAND_LATTICE;
-    if (P.hi_order)
-        return shared ? launch_search_fast<true, true, VALUE>(P, B, A, st) : launch_search_fast<false, true, VALUE>(P, B, A, st);
-    return shared ? launch_search_fast<true, false, VALUE>(P, B, A, st) : launch_search_fast<false, false, VALUE>(P, B, A, st);
+    if (P.hi_order) {
+        if (P.cand_mode == CAND_LATTICE) return launch_search_fast<CAND_LATTICE, true, VALUE>(P, B, A, st);
+        if (P.cand_mode == CAND_RAMP_HOLD) return launch_search_fast<CAND_RAMP_HOLD, true, VALUE>(P, B, A, st);
+        return launch_search_fast<CAND_TABLE, true, VALUE>(P, B, A, st);
+    }
+    if (P.cand_mode == CAND_LATTICE) return launch_search_fast<CAND_LATTICE, false, VALUE>(P, B, A, st);
+    if (P.cand_mode == CAND_RAMP_HOLD) return launch_search_fast<CAND_RAMP_HOLD, false, VALUE>(P, B, A, st);
+    return launch_search_fast<CAND_TABLE, false, VALUE>(P, B, A, st);
 }
 
 template <>
@@ -578,6 +632,22 @@ hipError_t launch_value<float>(const KP& P, int B, const DevNet<float>& net, con
 }
 
 template <typename T>
+hipError_t launch_refine(const KP& P, int B, int W, const SolveArgs<T>& A, double* u_prev_d, double* cpar, int first,
+                         hipStream_t st) {
+    if (first) {
+        hipLaunchKernelGGL((to_double_kernel<T>), dim3(((size_t)B * 2 + 255) / 256), dim3(256), 0, st, (size_t)B * 2, A.u_prev,
+                           u_prev_d);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(refine_targets_kernel, dim3((B + 255) / 256), dim3(256), 0, st, P, B, W, A.part_J, A.part_c, u_prev_d,
+                       cpar, first);
+    return hipGetLastError();
+}
+template hipError_t launch_refine<float>(const KP&, int, int, const SolveArgs<float>&, double*, double*, int, hipStream_t);
+template hipError_t launch_refine<double>(const KP&, int, int, const SolveArgs<double>&, double*, double*, int, hipStream_t);
+
+template <typename T>
 hipError_t launch_reduce(int B, int W, const SolveArgs<T>& A, hipStream_t st) {
     hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((B + 255) / 256), dim3(256), 0, st, B, W, A.part_J, A.part_c,
                        A.cost_out, A.argmin_out, A.status_out);
@@ -586,50 +656,57 @@ hipError_t launch_reduce(int B, int W, const SolveArgs<T>& A, hipStream_t st) {
 template hipError_t launch_reduce<float>(int, int, const SolveArgs<float>&, hipStream_t);
 template hipError_t launch_reduce<double>(int, int, const SolveArgs<double>&, hipStream_t);
 
-template <bool LATTICE, bool HI>
+template <int CAND, bool HI>
 static hipError_t launch_emit_fast(const KP& P, int B, int W, const SolveArgs<float>& A, hipStream_t st) {
-    hipLaunchKernelGGL((emit_fast_kernel<LATTICE, HI>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, W, A.x0, A.u_prev,
-                       A.kparams, A.flags, A.obs, A.table, A.cinf, A.part_J, A.part_c, A.cost_out, A.argmin_out,
+    hipLaunchKernelGGL((emit_fast_kernel<CAND, HI>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, W, A.x0, A.u_prev,
+                       A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.cost_out, A.argmin_out,
                        A.status_out, A.x_out, A.u_out);
     return hipGetLastError();
 }
 // float path: W per-slice partials per scenario are reduced here; double path: argmin_out is already final
 template <>
 hipError_t launch_emit<float>(const KP& P, int B, int W, const SolveArgs<float>& A, hipStream_t st) {
-    const bool lat = P.cand_mode == CAND_LATTICE;
-    if (P.hi_order) return lat ? launch_emit_fast<true, true>(P, B, W, A, st) : launch_emit_fast<false, true>(P, B, W, A, st);
-    return lat ? launch_emit_fast<true, false>(P, B, W, A, st) : launch_emit_fast<false, false>(P, B, W, A, st);
+    if (P.hi_order) {
+        if (P.cand_mode == CAND_LATTICE) return launch_emit_fast<CAND_LATTICE, true>(P, B, W, A, st);
+        if (P.cand_mode == CAND_RAMP_HOLD) return launch_emit_fast<CAND_RAMP_HOLD, true>(P, B, W, A, st);
+        return launch_emit_fast<CAND_TABLE, true>(P, B, W, A, st);
+    }
+    if (P.cand_mode == CAND_LATTICE) return launch_emit_fast<CAND_LATTICE, false>(P, B, W, A, st);
+    if (P.cand_mode == CAND_RAMP_HOLD) return launch_emit_fast<CAND_RAMP_HOLD, false>(P, B, W, A, st);
+    return launch_emit_fast<CAND_TABLE, false>(P, B, W, A, st);
 }
 template <>
 hipError_t launch_emit<double>(const KP& P, int B, int, const SolveArgs<double>& A, hipStream_t st) {
     hipLaunchKernelGGL((emit_kernel<ExactStepper<double>, double>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, A.x0,
-                       A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.argmin_out, A.x_out, A.u_out);
+                       A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.argmin_out, A.x_out, A.u_out);
     return hipGetLastError();
 }
 
-template <bool LATTICE, bool HI>
+template <int CAND, bool HI>
 static hipError_t launch_rollout_all_fast(const KP& P, int B, const SolveArgs<float>& A, float* X_all, float* U_all,
                                           float* cost_all, uint32_t* viol_all, hipStream_t st) {
-    hipLaunchKernelGGL((rollout_all_fast_kernel<LATTICE, HI>), dim3((B + 3) / 4), dim3(256), 0, st, P, B, A.x0, A.u_prev,
-                       A.kparams, A.flags, A.obs, A.table, A.cinf, X_all, U_all, cost_all, viol_all, A.rec_sN, A.rec_vN,
+    hipLaunchKernelGGL((rollout_all_fast_kernel<CAND, HI>), dim3((B + 3) / 4), dim3(256), 0, st, P, B, A.x0, A.u_prev,
+                       A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, X_all, U_all, cost_all, viol_all, A.rec_sN, A.rec_vN,
                        A.rec_J, A.rec_viol);
     return hipGetLastError();
 }
 template <>
 hipError_t launch_rollout_all<float>(const KP& P, int B, const SolveArgs<float>& A, float* X_all, float* U_all,
                                      float* cost_all, uint32_t* viol_all, hipStream_t st) {
-    const bool lat = P.cand_mode == CAND_LATTICE;
-    if (P.hi_order)
-        return lat ? launch_rollout_all_fast<true, true>(P, B, A, X_all, U_all, cost_all, viol_all, st)
-                   : launch_rollout_all_fast<false, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
-    return lat ? launch_rollout_all_fast<true, false>(P, B, A, X_all, U_all, cost_all, viol_all, st)
-               : launch_rollout_all_fast<false, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+    if (P.hi_order) {
+        if (P.cand_mode == CAND_LATTICE) return launch_rollout_all_fast<CAND_LATTICE, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+        if (P.cand_mode == CAND_RAMP_HOLD) return launch_rollout_all_fast<CAND_RAMP_HOLD, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+        return launch_rollout_all_fast<CAND_TABLE, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+    }
+    if (P.cand_mode == CAND_LATTICE) return launch_rollout_all_fast<CAND_LATTICE, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+    if (P.cand_mode == CAND_RAMP_HOLD) return launch_rollout_all_fast<CAND_RAMP_HOLD, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+    return launch_rollout_all_fast<CAND_TABLE, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
 }
 template <>
 hipError_t launch_rollout_all<double>(const KP& P, int B, const SolveArgs<double>& A, double* X_all, double* U_all,
                                       double* cost_all, uint32_t* viol_all, hipStream_t st) {
     hipLaunchKernelGGL((rollout_all_kernel<ExactStepper<double>, double>), dim3((B + 3) / 4), dim3(256), 0, st, P, B,
-                       A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, X_all, U_all, cost_all, viol_all,
+                       A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, X_all, U_all, cost_all, viol_all,
                        A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
     return hipGetLastError();
 }

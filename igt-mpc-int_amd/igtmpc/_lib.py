@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libigtmpc.so')
 
 IGT_MEM_DEVICE, IGT_MEM_HOST = 0, 1
-IGT_CAND_LATTICE, IGT_CAND_TABLE = 0, 1
+IGT_CAND_LATTICE, IGT_CAND_TABLE, IGT_CAND_RAMP_HOLD = 0, 1, 2
 IGT_COST_PROGRESS, IGT_COST_VALUE_NET = 0, 1
 IGT_FLAG_ABS_HEADING = 1
 VIOL_BITS = dict(box_v=1, box_u=2, rate=4, ey=8, terminal=16, collision=32, nonfinite=64)
@@ -21,7 +21,8 @@ class igt_params(C.Structure):
                 ('dt', C.c_double), ('l_r', C.c_double), ('l_f', C.c_double),
                 ('v_min', C.c_double), ('v_max', C.c_double), ('a_min', C.c_double), ('a_max', C.c_double),
                 ('df_max', C.c_double), ('jerk_limit', C.c_double), ('steer_rate_limit', C.c_double),
-                ('ey_lim', C.c_double), ('d_min', C.c_double), ('w_u', C.c_double), ('feas_tol', C.c_double)]
+                ('ey_lim', C.c_double), ('d_min', C.c_double), ('w_u', C.c_double), ('feas_tol', C.c_double),
+                ('refine_iters', C.c_int32), ('reserved', C.c_int32)]
 
 
 # every symbol include/igtmpc.h declares: name -> (restype, argtypes)

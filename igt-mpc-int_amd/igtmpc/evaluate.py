@@ -47,7 +47,7 @@ def initial_states(rng, route_pairs):
 
 
 def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=256, n_rk4=4, device=0,
-                    dtype='f32', rotation=None, cand_mode='lattice', verbose=False):
+                    dtype='f32', rotation=None, cand_mode='ramp_hold', refine_iters=0, verbose=False):
     rng = np.random.default_rng(seed)                                   # evaluate.py:35, 56
     E, M = num_samples, 2
     M_sim = int(T_sim / dt)                                             # evaluate.py:83-84
@@ -57,7 +57,8 @@ def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=
     absh = R.TABLES['abs_heading'][rid]
     flags = absh.astype(np.uint32).reshape(-1)
     u_prev = np.tile(np.array([0.1, 0.0]), (E, M, 1))                   # evaluate.py:419
-    solver = BatchSolver(N=N, dt=dt, n_rk4=n_rk4, C=C, n_obs=M - 1, device=device, dtype=dtype, cand_mode=cand_mode)
+    solver = BatchSolver(N=N, dt=dt, n_rk4=n_rk4, C=C, n_obs=M - 1, device=device, dtype=dtype, cand_mode=cand_mode,
+                         refine_iters=refine_iters if cand_mode == 'ramp_hold' else 0)
     solver.set_cinf(*cinf_halfplanes(dt=dt, jerk=solver.params.jerk_limit))
     stepper = BatchSolver(N=1, dt=dt, n_rk4=n_rk4, C=64, n_obs=0, device=device, dtype='f64')
     npdt = solver.np_dtype

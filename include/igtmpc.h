@@ -47,8 +47,9 @@ enum { IGT_MEM_DEVICE = 0, IGT_MEM_HOST = 1 };
 enum {
     IGT_CAND_LATTICE = 0,  /* G x G lattice of constant per-step (da, ddf) increments */
     IGT_CAND_TABLE = 1,    /* explicit table U[C,2,N] shared by every scenario         */
-    IGT_CAND_RAMP_HOLD = 2 /* G x G: da_i held for the horizon; steering ramps at +/-rate
-                              towards one of G target angles and holds it             */
+    IGT_CAND_RAMP_HOLD = 2 /* G x G: a and df ramp at the rate limits towards one of G targets each and hold
+                              it; targets are dense around u_prev (first pass) and, with refine_iters > 0,
+                              re-centred on the previous pass's winner with the spacing of its grid cell  */
 };
 
 /* cost (mpc.py:356-373) */
@@ -93,6 +94,8 @@ typedef struct igt_params {
     double d_min;            /* 2*ca_radius, mpc.py:45 */
     double w_u;              /* 0.05, mpc.py:362 */
     double feas_tol;         /* inequality verdicts are g <= feas_tol */
+    int32_t refine_iters;    /* IGT_CAND_RAMP_HOLD only: extra search passes around the winner (0..4) */
+    int32_t reserved;
 } igt_params;
 
 /* Fills *p with the reference's numbers: N=20, dt=0.1, n_rk4=4, C=256, n_obs=1,

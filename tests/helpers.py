@@ -30,7 +30,7 @@ def oracle_solve(batch, P, C=256, cinf=None, U=None):
                          return_all=True)
 
 
-def ambiguous_mask(ref, P, eps_margin=2e-5, eps_cost=2e-5, eps_bp=2e-5, bp=None):
+def ambiguous_mask(ref, P, eps_margin=2e-5, eps_cost=2e-5, eps_bp=2e-5, bp=None, ties=True):
     """Scenarios whose arg-min is decided inside float32 noise (documented in DESIGN.md):
     some candidate that could win sits within eps of a constraint threshold, or the best
     two feasible costs are closer than eps, or a stage argument of a contender lies
@@ -42,8 +42,9 @@ def ambiguous_mask(ref, P, eps_margin=2e-5, eps_cost=2e-5, eps_bp=2e-5, bp=None)
     near_thr = np.abs(g - P.feas_tol) < eps_margin
     amb = (contender & near_thr).any(axis=1)
     srt = np.sort(Jm, axis=1)
-    with np.errstate(invalid='ignore'):
-        amb |= (srt[:, 1] - srt[:, 0]) < eps_cost
+    if ties:
+        with np.errstate(invalid='ignore'):
+            amb |= (srt[:, 1] - srt[:, 0]) < eps_cost
     if bp is not None:
         amb |= (contender & (bp < eps_bp)).any(axis=1)
     return amb
