@@ -100,6 +100,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=4096, help='scenarios per GPU per step (BASELINE config 2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--gt', type=int, default=0, metavar='SC',
+                    help='gt_mpc cost with the shipped value net of scenario SC (1 or 3; BASELINE configs[4]); 0 = mpc cost')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -122,8 +124,16 @@ def main():
     batch = make_batch(B, N=N, dtype=np.float32, offset=rank * B)
     dargs = [torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda(dev)
              for a in (batch['x0'], batch['u_prev'], batch['kparams'], batch['flags'], batch['obs_xy'])]
-    solver = BatchSolver(N=N, C=C, n_obs=1, device=dev, dtype='f32')
+    solver = BatchSolver(N=N, C=C, n_obs=1, device=dev, dtype='f32', cost_mode='value_net' if args.gt else 'progress')
     solver.set_cinf(*cinf_halfplanes(dt=solver.params.dt, jerk=solver.params.jerk_limit))
+    if args.gt:
+        g = np.load(os.path.join(ROOT, 'tests', 'golden', 'value_net_golden.npz'))
+        layers, i = [], 0
+        while f'sc{args.gt}_W{i}' in g:
+            layers.append((g[f'sc{args.gt}_W{i}'], g[f'sc{args.gt}_b{i}']))
+            i += 1
+        solver.set_value_net(layers)      # identity whitening: the reference's statistics are not shipped
+        dargs += [torch.from_numpy(batch['tv_sv']).cuda(dev), torch.from_numpy(batch['enc']).cuda(dev)]
     out = solver.solve(*dargs)
 
     def step():
@@ -168,16 +178,17 @@ def main():
         value = B * n_gpus * args.steps / elapsed
         bytes_per_launch = (rd + 12) * B          # search kernel: reads inputs, writes cost/argmin/status
         ach = bytes_per_launch / (search_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, valu_busy = None, None      # PMC figures of the committed rocprofv3 run of this same command
         tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not args.gt:
             try:
                 with open(tpath) as f:
                     tj = json.load(f)
                 if tj.get('batch') == B:
                     traffic = tj.get('search_kernel_hbm_bytes_per_launch')
+                    valu_busy = tj.get('derived', {}).get('simd_valu_busy_fraction')
             except Exception:
-                traffic = None
+                traffic, valu_busy = None, None
         line = {
             'metric': 'mpc_solves_per_sec', 'value': value, 'unit': 'solves/s', 'n_gpus': n_gpus,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
@@ -188,20 +199,23 @@ def main():
                                    f'(BASELINE configs[1])',
                        'arithmetic': 'float32 stage derivatives + float64 state accumulators, cost and verdicts',
                        'parallelism': f'scenario shards x{n_gpus}, all-gather of u*[:, :, 0]' if n_gpus > 1 else 'single GPU',
+                       'cost': f'gt_mpc value net V_GT_sc{args.gt} ({len(layers) - 1} hidden layers, identity normalisation)' if args.gt else 'mpc progress cost',
                        'feasible_fraction': feasible},
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'search_kernel<FastStepper,float>', 'kernel_ms': search_ms,
+                         'kernel': 'search_fast_kernel (+ value kernels in gt mode)', 'kernel_ms': search_ms,
                          'algorithmic_bytes_per_solve': rd + 12,
                          'note': 'the path is FP32-VALU-bound (arithmetic intensity ~1e4 flop/B); see valu_roofline'},
             'valu_roofline': {'bound': 'fp32_valu', 'achieved': B / (search_ms * 1e-3) * FLOP_EQ_PER_SOLVE / 1e12,
                               'peak': FP32_VALU_PEAK_TFLOPS, 'unit': 'TFLOP-eq/s',
                               'frac': B / (search_ms * 1e-3) * FLOP_EQ_PER_SOLVE / 1e12 / FP32_VALU_PEAK_TFLOPS,
-                              'flop_eq_per_solve': FLOP_EQ_PER_SOLVE},
+                              'flop_eq_per_solve': FLOP_EQ_PER_SOLVE, 'simd_valu_busy_pmc': valu_busy,
+                              'note': 'flop-equivalents are the ALGORITHMIC count of SURVEY 8d (one sincos per RK stage at 20 flop); '
+                                      'the kernel reaches them with fewer instructions, so frac can exceed the pipe utilisation'},
             'kernels_ms': {'search': search_ms, 'emit': emit_ms},
             'whole_solve_bytes': rd + wr,
         }
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline and not args.gt:
             line['cpu_baseline'] = cpu_baseline(batch, N, C)
         print(json.dumps(line), flush=True)
     solver.close()

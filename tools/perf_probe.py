@@ -47,7 +47,20 @@ def run(dtype, B, nc, iters=5, straight=None, net=None):
           f'-> {B / (ms + me) * 1e3 / 1e6:7.3f} M solves/s (kernels)  feasible {np.mean(st == 0):.2f}', flush=True)
 
 
+def host_mode(B=4096):
+    b = make_batch(B, dtype=np.float32)
+    a = (b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy'])
+    with BatchSolver(dtype='f32') as s:
+        s.solve(*a)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            s.solve(*a)
+        dt = (time.perf_counter() - t0) / 20
+    print(f'host buffers (PCIe-inclusive, staged) B={B}: {dt * 1e3:.3f} ms/solve-call -> {B / dt / 1e6:.3f} M solves/s', flush=True)
+
+
 if __name__ == '__main__':
+    host_mode()
     run('f32', 4096, 2)
     run('f32', 65536, 2)
     g = np.load(os.path.join(ROOT, 'tests', 'golden', 'value_net_golden.npz'))
