@@ -104,3 +104,20 @@ def test_oracle_solve_edge_cases():
     # abs-heading flag (mpc.py:231-234)
     x = O.apply_flags(np.array([[0, 0, 0, 0, 0, 1, -3.0]]), np.array([1], dtype=np.uint32))
     assert x[0, 6] == 3.0
+
+
+def test_nlp_quality_yardstick_runs():
+    """oracle/nlp_quality.py (scipy SLSQP on the single-shooting restatement of the mpc.py NLP): polishing the
+    shooting winner never raises the cost and stays feasible.  Quality metric, not parity."""
+    import nlp_quality as Q
+    from igtmpc.cinf import cinf_halfplanes
+    from igtmpc.scenarios import make_batch
+    P = O.Params()
+    cinf = cinf_halfplanes()
+    b = make_batch(16, dtype=np.float64)
+    sol = O.solve_batch_refined(b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy'], *cinf, P, refine_iters=1)[-1]
+    idx = [i for i in range(16) if sol['status'][i] == 0][:2]
+    rows = Q.gap_report(b, sol, cinf, P, idx)
+    assert len(rows) >= 1
+    assert (rows[:, 3] > -1e-6).all() and (rows[:, 3] < 1.5).all()
+    assert np.allclose(rows[:, 1], sol['cost'][rows[:, 0].astype(int)], atol=1e-9)   # same cost function
