@@ -1,17 +1,16 @@
 // igt_device.h -- device-side arithmetic of the batched shooting solver (gfx950).
 //
-// Mapping: one 64-lane wavefront owns one scenario; lane l rolls
-// candidates l, l+64, l+128, ... (NC of them interleaved in registers per pass), so every
-// per-scenario input is wave-uniform and lives in SGPRs, the recurrence over the horizon
-// runs in VGPRs, and the arg-min over candidates is one 6-step wave butterfly.
+// Mapping: a 64-lane wavefront owns one scenario (float path: one 128-candidate
+// slice of it); lanes roll different candidates, so every per-scenario input is wave-uniform and lives in
+// SGPRs, the recurrence over the horizon runs in VGPRs, and the arg-min over candidates is one 6-step wave
+// butterfly.
 //
-// Two steppers implement one control step of the reference's RK4 Frenet bicycle model
-// (kinematic_bicycle_model_frenet.py:70-127; casadi twin 129-185 used by mpc.py:201-209):
-//   ExactStepper<T> : operation-for-operation what the reference / the float64 oracle does.
-//   FastStepper     : float derivatives + double state accumulators, stage angles by
-//                     rotating the sub-step's (sin,cos) through the small stage offsets.
-// Cost (mpc.py:356-373) and constraints (mpc.py:177-180, 223-226, 296-321) are evaluated
-// in double on the step-boundary states by Bookkeeper, shared by both steppers.
+// This header holds what both precisions share (kernel parameters, candidate generation, verdict helpers)
+// and the parity path: ExactStepper<T> performs one control step of the reference's RK4 Frenet bicycle
+// model (kinematic_bicycle_model_frenet.py:70-127; casadi twin 129-185 used by mpc.py:201-209) operation for
+// operation as the float64 oracle does, and rollout_pass evaluates cost (mpc.py:356-373) and constraints
+// (mpc.py:177-180, 223-226, 296-321) in double on the step-boundary states.  The float32 production path
+// (two candidates per lane as packed pairs) is igt_fast.h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -164,158 +163,6 @@ struct ExactStepper {
             psi = psi + h6 * (k1[6] + 2 * k2[6] + 2 * k3[6] + k4[6]);
         }
         st.s = s; st.ey = ey; st.ep = ep; st.v = v; st.x = x; st.y = y; st.psi = psi;
-    }
-};
-
-// ---------------------------------------------------------------------------------------
-// FastStepper: the same RK4 stages with float derivatives.
-//   * state accumulators are double (80 float-rounded increments would otherwise random-walk
-//     to ~1e-5 in s/x/y); every stage ARGUMENT is "base + small offset":
-//       - curvature switch K(s') is decided on float(s - b) + offset, i.e. relative to the
-//         break-point, so the comparison is exact to ~1e-9 near the switch;
-//       - sin/cos of (beta+epsi') and (psi'+beta) come from rotating the sub-step's base
-//         (sin,cos) by the offset with a short polynomial (|offset| <= h*|rate| << 1);
-//         the base pair is refreshed with sincosf once per control step.
-//   * psi and v are not coupled back, so their stage values are closed-form:
-//       v_j = v + c_j a,   psi'_j = psi + (h/2) v_{j-1} sin(beta)/l_r  (quirk :111 included)
-//     and the x,y rows collapse to one rotation of (A,B) = sum w_j v_j (cos,sin)(offset_j).
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void small_sincos(float d, float& sd, float& cd) {
-    // |d| <= 0.5: truncation <= 2e-9 (sin), 3e-10 (cos)
-    const float d2 = d * d;
-    float p = fmaf(d2, -1.0f / 5040.0f, 1.0f / 120.0f);
-    p = fmaf(d2, p, -1.0f / 6.0f);
-    sd = fmaf(d * d2, p, d);
-    float q = fmaf(d2, 1.0f / 40320.0f, -1.0f / 720.0f);
-    q = fmaf(d2, q, 1.0f / 24.0f);
-    q = fmaf(d2, q, -0.5f);
-    cd = fmaf(d2, q, 1.0f);
-}
-
-__device__ __forceinline__ void rotate(float& s, float& c, float sd, float cd) {
-    const float s_ = fmaf(s, cd, c * sd);
-    const float c_ = fmaf(c, cd, -(s * sd));
-    s = s_; c = c_;
-}
-
-// sin/cos of a double angle: float sincosf on the rounded angle + first-order residual
-__device__ __forceinline__ void sincos_hi_lo(double ang, float& s, float& c) {
-    const float hi = (float)ang;
-    const float lo = (float)(ang - (double)hi);
-    float sh, ch;
-    sincosf(hi, &sh, &ch);
-    s = fmaf(ch, lo, sh);
-    c = fmaf(-sh, lo, ch);
-}
-
-struct FastStepper {
-    struct State { double x, y, s, ey, ep, v, psi; };
-    struct Beta { float cb, sb, sblr; };
-    float h, hh, h6, kv, inv_lr, lr_ratio;
-    double b0, b1, hd;
-    int n_rk4;
-
-    __device__ __forceinline__ void init(const KP& P, double b0_, double b1_, double kv_) {
-        h = (float)P.h; hh = (float)(P.h / 2); h6 = (float)(P.h / 6);
-        hd = P.h;
-        kv = (float)kv_; inv_lr = (float)(1.0 / P.l_r); lr_ratio = (float)P.lr_ratio;
-        b0 = b0_; b1 = b1_;
-        n_rk4 = P.n_rk4;
-    }
-    __device__ __forceinline__ void set(State& st, const double (&x0)[7]) const {
-        st.x = x0[0]; st.y = x0[1]; st.s = x0[2]; st.ey = x0[3]; st.ep = x0[4]; st.v = x0[5]; st.psi = x0[6];
-    }
-    __device__ __forceinline__ void get(const State& st, double (&o)[7]) const {
-        o[0] = st.x; o[1] = st.y; o[2] = st.s; o[3] = st.ey; o[4] = st.ep; o[5] = st.v; o[6] = st.psi;
-    }
-    __device__ __forceinline__ Beta prep(double df) const {
-        // beta = atan(t), t = l_r/(l_f+l_r) tan(df)  ->  cos(beta) = 1/sqrt(1+t^2), sin(beta) = t cos(beta)
-        const float t = lr_ratio * tanf((float)df);
-        Beta B;
-        B.cb = rsqrtf(fmaf(t, t, 1.0f));
-        B.sb = t * B.cb;
-        B.sblr = B.sb * inv_lr;
-        return B;
-    }
-    __device__ __forceinline__ float curv(float d0, float d1) const {
-        return (d0 >= 0.0f ? kv : 0.0f) - (d1 >= 0.0f ? kv : 0.0f);
-    }
-    __device__ __forceinline__ void step(State& st, double a_, const Beta& B) const {
-        const float a = (float)a_;
-        // base (sin,cos) of theta1 = beta+epsi and theta2 = psi+beta at the control-step start
-        float s1, c1, s2, c2;
-        sincos_hi_lo(st.ep, s1, c1);
-        rotate(s1, c1, B.sb, B.cb);
-        sincos_hi_lo(st.psi, s2, c2);
-        rotate(s2, c2, B.sb, B.cb);
-        const float ha = hh * a;
-        for (int j = 0; j < n_rk4; ++j) {
-            const float v1 = (float)st.v;
-            const float ey0 = (float)st.ey;
-            const float d0 = (float)(st.s - b0);
-            const float d1 = (float)(st.s - b1);
-            const float v2 = v1 + ha;          // stages 2,3
-            const float v4 = v2 + ha;          // stage 4
-            // ---- stage 1
-            float K = curv(d0, d1);
-            float ds1 = v1 * c1 * __builtin_amdgcn_rcpf(fmaf(-K, ey0, 1.0f));
-            float de1 = v1 * s1;
-            const float w1 = v1 * B.sblr;
-            float dp1 = fmaf(-ds1, K, w1);
-            // ---- stage 2 (arguments base + h/2 k1)
-            float sd, cd, sa, ca;
-            small_sincos(hh * dp1, sd, cd);
-            sa = s1; ca = c1; rotate(sa, ca, sd, cd);
-            float o = hh * ds1;
-            K = curv(d0 + o, d1 + o);
-            float ds2 = v2 * ca * __builtin_amdgcn_rcpf(fmaf(-K, fmaf(hh, de1, ey0), 1.0f));
-            float de2 = v2 * sa;
-            const float w2 = v2 * B.sblr;
-            float dp2 = fmaf(-ds2, K, w2);
-            // ---- stage 3 (base + h/2 k2)
-            small_sincos(hh * dp2, sd, cd);
-            sa = s1; ca = c1; rotate(sa, ca, sd, cd);
-            o = hh * ds2;
-            K = curv(d0 + o, d1 + o);
-            float ds3 = v2 * ca * __builtin_amdgcn_rcpf(fmaf(-K, fmaf(hh, de2, ey0), 1.0f));
-            float de3 = v2 * sa;
-            float dp3 = fmaf(-ds3, K, w2);
-            // ---- stage 4 (base + h k3)
-            small_sincos(h * dp3, sd, cd);
-            sa = s1; ca = c1; rotate(sa, ca, sd, cd);
-            o = h * ds3;
-            K = curv(d0 + o, d1 + o);
-            float ds4 = v4 * ca * __builtin_amdgcn_rcpf(fmaf(-K, fmaf(h, de3, ey0), 1.0f));
-            float de4 = v4 * sa;
-            const float w4 = v4 * B.sblr;
-            float dp4 = fmaf(-ds4, K, w4);
-            // ---- Cartesian rows: psi offsets are h/2 w1 (stage 2) and h/2 w2 (stages 3 AND 4, :111)
-            float sd2, cd2, sd3, cd3;
-            small_sincos(hh * w1, sd2, cd2);
-            small_sincos(hh * w2, sd3, cd3);
-            const float v34 = fmaf(2.0f, v2, v4);
-            const float A = fmaf(v34, cd3, fmaf(2.0f * v2, cd2, v1));
-            const float Bq = fmaf(v34, sd3, 2.0f * v2 * sd2);
-            const float dx = fmaf(c2, A, -(s2 * Bq));
-            const float dy = fmaf(s2, A, c2 * Bq);
-            // ---- combine (frenet.py:113-119)
-            const float is = h6 * (ds1 + 2.0f * ds2 + 2.0f * ds3 + ds4);
-            const float ie = h6 * (de1 + 2.0f * de2 + 2.0f * de3 + de4);
-            const float ip = h6 * (dp1 + 2.0f * dp2 + 2.0f * dp3 + dp4);
-            const float iw = h6 * (w1 + 4.0f * w2 + w4);
-            st.s += (double)is;
-            st.ey += (double)ie;
-            st.ep += (double)ip;
-            st.psi += (double)iw;
-            st.x += (double)(h6 * dx);
-            st.y += (double)(h6 * dy);
-            st.v = fma(hd, a_, st.v);
-            // base angles for the next sub-step
-            small_sincos(ip, sd, cd);
-            rotate(s1, c1, sd, cd);
-            small_sincos(iw, sd, cd);
-            rotate(s2, c2, sd, cd);
-        }
     }
 };
 

@@ -513,6 +513,35 @@ __global__ __launch_bounds__(256) void forecast_kernel(KP P, int B, const double
         for (int k = 0; k <= N; ++k) { ox[k] = (T)-20; oy[k] = (T)-20; }
 }
 
+// float path of igt_frenet_step_f32: one control step through the same pair arithmetic the solver uses
+template <bool HI>
+__global__ __launch_bounds__(256) void frenet_step_fast_kernel(KP P, int n, const float* __restrict__ x,
+                                                               const float* __restrict__ u,
+                                                               const float* __restrict__ kparams,
+                                                               float* __restrict__ x_next) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    KP P1 = P;
+    P1.N = 1;
+    P1.cand_mode = CAND_TABLE;
+    Scenario<float> S;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) S.x0[k] = (double)x[(size_t)i * 7 + k];
+    S.a_prev = 0.0; S.df_prev = 0.0;
+    S.b0 = (double)kparams[(size_t)i * 3 + 0]; S.b1 = (double)kparams[(size_t)i * 3 + 1]; S.kv = (double)kparams[(size_t)i * 3 + 2];
+    S.cpar[0] = S.cpar[1] = S.cpar[2] = S.cpar[3] = 0.0;
+    S.obs = nullptr;
+    const double tab[2] = {(double)u[(size_t)i * 2 + 0], (double)u[(size_t)i * 2 + 1]};   // table [1 candidate, 2, N = 1]
+    float out[7 * 2];
+    PairSink<float> sink{{out, nullptr}, {nullptr, nullptr}, 1};
+    const int cidx[2] = {0, 0};
+    double J[2], sN[2], vN[2];
+    unsigned viol[2];
+    rollout_pair<CAND_TABLE, HI, false, false, float>(P1, S, cidx, tab, nullptr, sink, J, viol, sN, vN);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) x_next[(size_t)i * 7 + k] = out[k * 2 + 1];
+}
+
 // kinematic_bicycle_model.py:27-31, T steps per trajectory
 template <typename T>
 __global__ __launch_bounds__(256) void cartesian_euler_kernel(int n, int steps, T dt, T l_r, T l_f,
@@ -714,8 +743,12 @@ hipError_t launch_rollout_all<double>(const KP& P, int B, const SolveArgs<double
 template <>
 hipError_t launch_frenet_step<float>(const KP& P, int n, const float* x, const float* u, const float* kparams,
                                      float* x_next, hipStream_t st) {
-    hipLaunchKernelGGL((frenet_step_kernel<FastStepper, float>), dim3((n + 255) / 256), dim3(256), 0, st, P, n, x, u,
-                       kparams, x_next);
+    if (P.hi_order)
+        hipLaunchKernelGGL((frenet_step_fast_kernel<true>), dim3((n + 255) / 256), dim3(256), 0, st, P, n, x, u, kparams,
+                           x_next);
+    else
+        hipLaunchKernelGGL((frenet_step_fast_kernel<false>), dim3((n + 255) / 256), dim3(256), 0, st, P, n, x, u, kparams,
+                           x_next);
     return hipGetLastError();
 }
 template <>

@@ -394,3 +394,57 @@ def test_ramp_hold_with_refinement_matches_oracle(igt, dtype, tol, eps):
     both = (passes[0]['status'] == 0) & (ref['status'] == 0)
     assert (ref['cost'][both] <= passes[0]['cost'][both] + 1e-12).all()
     assert (ref['cost'][both] < passes[0]['cost'][both] - 1e-6).any()
+
+
+@pytest.mark.parametrize('N,n_rk4,C,n_obs', [(10, 4, 256, 1), (40, 4, 64, 1), (20, 7, 64, 1), (20, 4, 1024, 1),
+                                             (20, 4, 256, 0), (20, 2, 256, 2), (20, 1, 256, 1)])
+def test_other_shapes_f32(igt, N, n_rk4, C, n_obs):
+    """float path at other discretisations (n_rk4 <= 2 switches to the longer offset polynomials), odd chunk
+    counts (C = 64) and many slices (C = 1024)."""
+    b = _batch(48, np.float32, N=N)
+    obs = np.concatenate([b['obs_xy']] * max(n_obs, 1), axis=1)[:, :n_obs]
+    if n_obs == 2:
+        obs[:, 1] += 3.0
+    obs = np.ascontiguousarray(obs)
+    with igt.BatchSolver(dtype='f32', N=N, n_rk4=n_rk4, C=C, n_obs=n_obs) as s:
+        P = oracle_params(s)
+        got = s.solve(b['x0'], b['u_prev'], b['kparams'], b['flags'], obs)
+    bb = dict(b, obs_xy=obs)
+    ref = oracle_solve(bb, P, C=C)
+    kp = b['kparams'].astype(np.float64)[:, None, :]
+    x0 = O.apply_flags(b['x0'].astype(np.float64), b['flags'])[:, None, :]
+    bp = O.breakpoint_distance(x0, ref['U'], kp, P)
+    amb = ambiguous_mask(ref, P, 2e-5, 2e-5, 2e-5, bp)
+    ok = ~amb
+    assert ok.mean() > 0.7
+    assert (got['argmin'][ok] == ref['argmin'][ok]).all() and (got['status'][ok] == ref['status'][ok]).all()
+    sol = ok & (ref['status'] == 0)
+    if sol.any():
+        assert rel_err(got['x'][sol], ref['x'][sol]).max() <= REL_TOL
+        assert rel_err(got['cost'][sol], ref['cost'][sol]).max() <= REL_TOL
+
+
+def test_value_net_with_ramp_hold_refinement_f64(igt, golden_dir):
+    """gt_mpc cost + ramp-hold candidates + one refinement pass (per-chunk partials feed the refinement)."""
+    layers = _nets(golden_dir)[1]
+    net = dict(layers=layers, Wn=np.eye(6), mu_f=np.zeros(6), sigma_t=1.0, mu_t=0.0)
+    b = _batch(96, np.float64)
+    f = lambda k: np.asarray(b[k], dtype=np.float64)
+    with igt.BatchSolver(dtype='f64', cost_mode='value_net', cand_mode='ramp_hold', refine_iters=1) as s:
+        P = oracle_params(s)
+        s.set_cinf(*_cinf())
+        s.set_value_net(**net)
+        got = s.solve(*_args(b), b['tv_sv'], b['enc'])
+    passes = O.solve_batch_refined(f('x0'), f('u_prev'), f('kparams'), b['flags'], f('obs_xy'), *_cinf(), P,
+                                   refine_iters=1, net=net, tv_sv=f('tv_sv'), enc=f('enc'))
+    amb = np.zeros(96, bool)
+    for r in passes:
+        amb |= ambiguous_mask(r, P, 1e-9, 1e-9)
+    ok = ~amb
+    ref = passes[-1]
+    assert ok.mean() > 0.9
+    assert (got['argmin'][ok] == ref['argmin'][ok]).all() and (got['status'][ok] == ref['status'][ok]).all()
+    sol = ok & (ref['status'] == 0)
+    assert sol.sum() > 10
+    assert rel_err(got['x'][sol], ref['x'][sol]).max() < 1e-9
+    assert rel_err(got['cost'][sol], ref['cost'][sol]).max() < 1e-9
