@@ -47,7 +47,14 @@ def initial_states(rng, route_pairs):
 
 
 def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=256, n_rk4=4, device=0,
-                    dtype='f32', rotation=None, cand_mode='ramp_hold', refine_iters=0, verbose=False):
+                    dtype='f32', rotation=None, cand_mode='ramp_hold', refine_iters=0, verbose=False,
+                    eval_mode='mpc', value_net=None):
+    """eval_mode 'mpc' (evaluate.py:370-639) or 'gt_mpc' (123-369: terminal value network in the cost; needs
+    value_net = dict(layers=[(W,b),...][, Wn, mu_f, sigma_t, mu_t]) -- the reference's normalisation statistics are
+    not shipped, identity by default)."""
+    gt = eval_mode == 'gt_mpc'
+    if gt and value_net is None:
+        raise ValueError("eval_mode='gt_mpc' needs value_net")
     rng = np.random.default_rng(seed)                                   # evaluate.py:35, 56
     E, M = num_samples, 2
     M_sim = int(T_sim / dt)                                             # evaluate.py:83-84
@@ -56,9 +63,19 @@ def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=
     kp = R.kparams(rid)                                                 # [E,M,3]
     absh = R.TABLES['abs_heading'][rid]
     flags = absh.astype(np.uint32).reshape(-1)
-    u_prev = np.tile(np.array([0.1, 0.0]), (E, M, 1))                   # evaluate.py:419
+    u_prev = np.tile(np.array([0.0 if gt else 0.1, 0.0]), (E, M, 1))    # evaluate.py:419 (mpc) / 171 (gt_mpc)
     solver = BatchSolver(N=N, dt=dt, n_rk4=n_rk4, C=C, n_obs=M - 1, device=device, dtype=dtype, cand_mode=cand_mode,
-                         refine_iters=refine_iters if cand_mode == 'ramp_hold' else 0)
+                         refine_iters=refine_iters if cand_mode == 'ramp_hold' else 0,
+                         cost_mode='value_net' if gt else 'progress')
+    if gt:
+        solver.set_value_net(**value_net)
+        # scenario encodings (mpc.py:336-337, utils.py:84-169): (e_ego, e_other) per problem
+        enc = np.zeros((E, M, 2))
+        for e, pair in enumerate(pairs):
+            code = R.scenario_encoding_sign(pair, R.scenario_of(pair))
+            enc[e, 0] = (code[0], code[1])
+            enc[e, 1] = (code[1], code[0])
+        enc = enc.reshape(E * M, 2)
     solver.set_cinf(*cinf_halfplanes(dt=dt, jerk=solver.params.jerk_limit))
     stepper = BatchSolver(N=1, dt=dt, n_rk4=n_rk4, C=64, n_obs=0, device=device, dtype='f64')
     npdt = solver.np_dtype
@@ -78,7 +95,10 @@ def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=
         other = slice(None, None, -1)
         ego_xyh = x[:, :, [0, 1, 6]].reshape(E * M, 3)
         opp = x[:, other][:, :, [0, 1, 2, 5]].reshape(E * M, 4)
-        obs, _tv = solver.forecast(ego_xyh.astype(npdt), opp.astype(npdt), u_prev[:, other, 0].reshape(-1).astype(npdt),
+        a_fc = u_prev[:, other, 0]
+        if gt and t == 0:                                               # evaluate.py:207-210: a = 0.09 (k+1) for agent k
+            a_fc = np.tile(0.09 * (np.arange(M)[::-1] + 1.0), (E, 1))
+        obs, tv = solver.forecast(ego_xyh.astype(npdt), opp.astype(npdt), a_fc.reshape(-1).astype(npdt),
                                    rid[:, other].reshape(-1).astype(np.int32),
                                    sol_x[:, other].reshape(E * M, 7, N + 1).astype(npdt),
                                    sol_u[:, other].reshape(E * M, 2, N).astype(npdt),
@@ -86,7 +106,8 @@ def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=
         # --- solve every (episode, agent) problem at once (evaluate.py:470-482)
         t0 = time.perf_counter()
         out = solver.solve(x.reshape(E * M, 7).astype(npdt), u_prev.reshape(E * M, 2).astype(npdt),
-                           kp.reshape(E * M, 3).astype(npdt), flags, obs)
+                           kp.reshape(E * M, 3).astype(npdt), flags, obs,
+                           tv if gt else None, enc.astype(npdt) if gt else None)
         solve_ms.append((time.perf_counter() - t0) * 1e3)
         ok = (out['status'] == 0).reshape(E, M)
         xs = out['x'].reshape(E, M, 7, N + 1).astype(np.float64)
@@ -124,10 +145,23 @@ def main():
     ap.add_argument('--num_samples', type=int, default=1)
     ap.add_argument('--N', type=int, default=20)
     ap.add_argument('--C', type=int, default=256)
-    ap.add_argument('--eval_mode', default='mpc', choices=['mpc'])
+    ap.add_argument('--eval_mode', default='mpc', choices=['mpc', 'gt_mpc'])
+    ap.add_argument('--value_net', default=None, help='gt_mpc: .npz with W0,b0,W1,b1,... (optionally prefixed, see --net_prefix)')
+    ap.add_argument('--net_prefix', default='', help="key prefix inside the npz, e.g. 'sc1_'")
     ap.add_argument('--verbose', action='store_true')
     a = ap.parse_args()
-    r = run_closed_loop(sc=a.sc, num_samples=a.num_samples, N=a.N, C=a.C, verbose=a.verbose)
+    net = None
+    if a.eval_mode == 'gt_mpc':
+        if not a.value_net:
+            ap.error('--eval_mode gt_mpc needs --value_net')
+        z = np.load(a.value_net)
+        layers, i = [], 0
+        while f'{a.net_prefix}W{i}' in z:
+            layers.append((z[f'{a.net_prefix}W{i}'], z[f'{a.net_prefix}b{i}']))
+            i += 1
+        net = dict(layers=layers)
+    r = run_closed_loop(sc=a.sc, num_samples=a.num_samples, N=a.N, C=a.C, verbose=a.verbose, eval_mode=a.eval_mode,
+                        value_net=net)
     print(json.dumps({'sc': a.sc, 'episodes': a.num_samples, 'routes': r['routes'][:4],
                       'infeasible_ratio_mean': r['infeasible_ratio'].mean(axis=0).tolist(),
                       'deadlock_rate': float(r['deadlock'].mean()),

@@ -169,3 +169,20 @@ def test_forecast_matches_oracle(golden_dir):
             assert rel_err(obs_raw[b, 0], ref_raw).max() < tol
             n_filtered += ref[0, 0] == -20.0
         assert 0.2 * B < n_filtered < 0.8 * B
+
+
+def test_closed_loop_gt_mpc_mode(golden_dir):
+    """evaluate.py --eval_mode gt_mpc counterpart: value network in the cost, (0,0) initial inputs, the first
+    step's special forecast; runs with the shipped sc1 checkpoint (identity normalisation)."""
+    from igtmpc.evaluate import run_closed_loop
+    v = np.load(f'{golden_dir}/value_net_golden.npz')
+    layers, i = [], 0
+    while f'sc1_W{i}' in v:
+        layers.append((v[f'sc1_W{i}'], v[f'sc1_b{i}']))
+        i += 1
+    r = run_closed_loop(sc=1, num_samples=4, N=20, T_sim=2.0, eval_mode='gt_mpc', value_net=dict(layers=layers))
+    assert r['x_data'].shape == (4, 14, 21) and np.isfinite(r['x_data']).all()
+    m = run_closed_loop(sc=1, num_samples=4, N=20, T_sim=2.0)
+    assert not np.array_equal(r['u_data'], m['u_data'])          # the terminal value changes the decisions
+    with pytest.raises(ValueError):
+        run_closed_loop(sc=1, num_samples=1, eval_mode='gt_mpc')
