@@ -48,10 +48,11 @@ def initial_states(rng, route_pairs):
 
 def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=256, n_rk4=4, device=0,
                     dtype='f32', rotation=None, cand_mode='ramp_hold', refine_iters=0, verbose=False,
-                    eval_mode='mpc', value_net=None):
+                    eval_mode='mpc', value_net=None, device_resident=False):
     """eval_mode 'mpc' (evaluate.py:370-639) or 'gt_mpc' (123-369: terminal value network in the cost; needs
     value_net = dict(layers=[(W,b),...][, Wn, mu_f, sigma_t, mu_t]) -- the reference's normalisation statistics are
-    not shipped, identity by default)."""
+    not shipped, identity by default).  device_resident=True keeps every per-step array in HBM (torch tensors;
+    forecast, solve, fallback step and the state update never leave the GPU) -- for thousands of episodes."""
     gt = eval_mode == 'gt_mpc'
     if gt and value_net is None:
         raise ValueError("eval_mode='gt_mpc' needs value_net")
@@ -79,6 +80,13 @@ def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=
     solver.set_cinf(*cinf_halfplanes(dt=dt, jerk=solver.params.jerk_limit))
     stepper = BatchSolver(N=1, dt=dt, n_rk4=n_rk4, C=64, n_obs=0, device=device, dtype='f64')
     npdt = solver.np_dtype
+
+    if device_resident:
+        out = _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc if gt else None, gt, E, M, N, M_sim, device)
+        solver.close()
+        stepper.close()
+        out['routes'] = pairs
+        return out
 
     x_data = np.zeros((E, 7 * M, M_sim + 1))
     u_data = np.zeros((E, 2 * M, M_sim))
@@ -139,6 +147,69 @@ def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=
                 routes=pairs, solve_ms=np.array(solve_ms))
 
 
+def _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc, gt, E, M, N, M_sim, device):
+    """The same time loop with every array resident in HBM (float64 state, solver-dtype views per call)."""
+    import torch
+    dev = torch.device('cuda', device)
+    td = torch.float32 if solver.dtype == 'f32' else torch.float64
+    T = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+    x, u_prev, kp = T(x), T(u_prev), T(kp)
+    kp_s = kp.reshape(E * M, 3).to(td).contiguous()
+    kp_d = kp.reshape(E * M, 3).contiguous()
+    flags_t = torch.as_tensor(flags.astype(np.int32), device=dev)
+    rid_o = torch.as_tensor(rid[:, ::-1].reshape(-1).astype(np.int32), device=dev)
+    enc_t = T(enc, td) if gt else None
+    x_data = torch.zeros((E, 7 * M, M_sim + 1), dtype=torch.float64, device=dev)
+    u_data = torch.zeros((E, 2 * M, M_sim), dtype=torch.float64, device=dev)
+    x_data[:, :, 0] = x.reshape(E, 7 * M)
+    infeasible = torch.zeros((E, M), dtype=torch.int64, device=dev)
+    have_sol = torch.zeros((E, M), dtype=torch.bool, device=dev)
+    sol_x = torch.zeros((E, M, 7, N + 1), dtype=td, device=dev)
+    sol_u = torch.zeros((E, M, 2, N), dtype=td, device=dev)
+    ix = torch.tensor([0, 1, 6], device=dev)
+    io = torch.tensor([0, 1, 2, 5], device=dev)
+    torch.cuda.synchronize(dev)
+    t_start = time.perf_counter()
+    for t in range(M_sim):
+        xo, uo = x.flip(1), u_prev.flip(1)
+        a_fc = uo[..., 0]
+        if gt and t == 0:
+            a_fc = torch.as_tensor(0.09 * (np.arange(M)[::-1] + 1.0), device=dev).expand(E, M)
+        hp = (have_sol.flip(1) & (t > 0)).reshape(-1).to(torch.int32).contiguous()
+        obs, tv = solver.forecast(x.index_select(2, ix).reshape(E * M, 3).to(td).contiguous(),
+                                  xo.index_select(2, io).reshape(E * M, 4).to(td).contiguous(),
+                                  a_fc.reshape(-1).to(td).contiguous(), rid_o,
+                                  sol_x.flip(1).reshape(E * M, 7, N + 1).contiguous(),
+                                  sol_u.flip(1).reshape(E * M, 2, N).contiguous(), hp)
+        out = solver.solve(x.reshape(E * M, 7).to(td).contiguous(), u_prev.reshape(E * M, 2).to(td).contiguous(), kp_s,
+                           flags_t, obs, tv if gt else None, enc_t)
+        ok = (out['status'] == 0).reshape(E, M)
+        xs = out['x'].reshape(E, M, 7, N + 1)
+        us = out['u'].reshape(E, M, 2, N)
+        v_now = x[..., 5]
+        a_fb = torch.where(v_now > 0, torch.full_like(v_now, A_MIN_POLICY), torch.zeros_like(v_now))
+        neg = v_now < 0
+        u_fb = torch.stack([torch.where(neg, torch.zeros_like(a_fb), a_fb), u_prev[..., 1]], dim=-1)
+        u_step = torch.stack([a_fb, u_prev[..., 1]], dim=-1)
+        nxt_fb = stepper.frenet_step(x.reshape(E * M, 7).contiguous(), u_step.reshape(E * M, 2).contiguous(),
+                                     kp_d).reshape(E, M, 7)
+        stop = x.clone()
+        stop[..., 5] = 0.0
+        nxt_fb = torch.where(neg[..., None], stop, nxt_fb)
+        x = torch.where(ok[..., None], xs[:, :, :, 1].to(torch.float64), nxt_fb)
+        u_prev = torch.where(ok[..., None], us[:, :, :, 0].to(torch.float64), u_fb)
+        infeasible += (~ok).to(torch.int64)
+        have_sol, sol_x, sol_u = ok, torch.nan_to_num(xs), torch.nan_to_num(us)
+        x_data[:, :, t + 1] = x.reshape(E, 7 * M)
+        u_data[:, :, t] = u_prev.reshape(E, 2 * M)
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t_start
+    xd = x_data.cpu().numpy()
+    return dict(x_data=xd, u_data=u_data.cpu().numpy(), infeasible_ratio=infeasible.cpu().numpy() / M_sim,
+                deadlock=(xd[:, 2::7, -1] <= 30).sum(axis=1) >= 2, solve_ms=np.full(M_sim, wall / M_sim * 1e3),
+                wall_s=wall)
+
+
 def main():
     ap = argparse.ArgumentParser(description='batched closed-loop evaluation (counterpart of evaluate.py --eval_mode mpc)')
     ap.add_argument('--sc', type=int, default=1)
@@ -149,6 +220,7 @@ def main():
     ap.add_argument('--value_net', default=None, help='gt_mpc: .npz with W0,b0,W1,b1,... (optionally prefixed, see --net_prefix)')
     ap.add_argument('--net_prefix', default='', help="key prefix inside the npz, e.g. 'sc1_'")
     ap.add_argument('--verbose', action='store_true')
+    ap.add_argument('--device_resident', action='store_true', help='keep all per-step arrays in HBM (torch tensors)')
     a = ap.parse_args()
     net = None
     if a.eval_mode == 'gt_mpc':
@@ -161,7 +233,7 @@ def main():
             i += 1
         net = dict(layers=layers)
     r = run_closed_loop(sc=a.sc, num_samples=a.num_samples, N=a.N, C=a.C, verbose=a.verbose, eval_mode=a.eval_mode,
-                        value_net=net)
+                        value_net=net, device_resident=a.device_resident)
     print(json.dumps({'sc': a.sc, 'episodes': a.num_samples, 'routes': r['routes'][:4],
                       'infeasible_ratio_mean': r['infeasible_ratio'].mean(axis=0).tolist(),
                       'deadlock_rate': float(r['deadlock'].mean()),

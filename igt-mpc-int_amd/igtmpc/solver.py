@@ -152,7 +152,10 @@ class BatchSolver:
             return getattr(stream, 'cuda_stream', stream)
         if torch_mode:
             import torch
-            return torch.cuda.current_stream(self.device).cuda_stream
+            # torch's default stream has handle 0, which the C ABI reads as "the handle's own stream":
+            # name the legacy default stream explicitly (hipStreamLegacy == (hipStream_t)1) so the
+            # kernels are ordered with the surrounding torch ops
+            return torch.cuda.current_stream(self.device).cuda_stream or 1
         return None
 
     # ------------------------------------------------------------------ the solve

@@ -16,7 +16,8 @@
  *     work is enqueued on `stream` and the call returns without synchronising)
  *     or IGT_MEM_HOST (the library stages through its own device buffers and
  *     synchronises before returning).
- *   - `stream` is a hipStream_t passed as void* (NULL = the handle's own stream).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the handle's own non-blocking stream; pass
+ *     hipStreamLegacy, (void*)1, to name the legacy default stream).
  *   - state order everywhere: [x, y, s, ey, epsi, v, psi]      (mpc.py:163)
  *   - array layouts are C-contiguous with the shapes written in the comments.
  *   - one handle per (device, thread); handles share no mutable state.
