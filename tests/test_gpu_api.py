@@ -197,3 +197,62 @@ def test_closed_loop_device_resident_equals_host_loop():
         # (also guards the stream ordering of device-mode calls against the surrounding torch ops)
         assert np.array_equal(a['x_data'], b['x_data']) and np.array_equal(a['u_data'], b['u_data'])
         assert np.array_equal(a['infeasible_ratio'], b['infeasible_ratio'])
+
+
+def test_mpc_planner_gt_mode(golden_dir):
+    """use_NN_cost2go=True (evaluate.py:191): the planner drives the value-net cost through the same call
+    sequence and agrees with the oracle."""
+    import igtmpc
+    from igtmpc import routes as R
+    v = np.load(f'{golden_dir}/value_net_golden.npz')
+    layers, i = [], 0
+    while f'sc1_W{i}' in v:
+        layers.append((v[f'sc1_W{i}'], v[f'sc1_b{i}']))
+        i += 1
+    net = dict(layers=layers, Wn=np.eye(6), mu_f=np.zeros(6), sigma_t=1.0, mu_t=0.0)
+    routes, agents, refs = _scene()
+    N = 20
+    pred = igtmpc.ConstantAccelerationModel(N=N, dt=0.1)
+    inputs = [igtmpc.VehicleAction({'a': 0.0, 'df': 0.0}) for _ in routes]
+    preds = pred.predict(agents, inputs, routes, refs)
+    P = O.Params(N=N)
+    with pytest.raises(ValueError):
+        igtmpc.MPC_Planner(N=N, dt=0.1, agents=agents, routes=routes, ref=refs, road_dim=(11.4, 50), ds_right=8.6,
+                           index=0, num_rk4_steps=4, use_NN_cost2go=True)            # no statistics / weights given
+    for i in range(2):
+        pl = igtmpc.MPC_Planner(N=N, dt=0.1, ca_radius=2.8, agents=agents, routes=routes, ref=refs, goals=None,
+                                road_dim=(11.4, 50), ds_right=8.6, index=i, num_rk4_steps=4, dtype='f64',
+                                use_NN_cost2go=True, value_net=net)
+        pl.update_initial_condition(agents[i], inputs[i])
+        pl.update_predictions(preds, raw_preds=preds)
+        x, u, ok = pl.solve()
+        st = agents[i]['state']
+        j = 1 - i
+        obs = np.array([[[[p.x for p in preds[j]], [p.y for p in preds[j]]]]])
+        e = R.scenario_encoding_sign(routes, R.scenario_of(routes))
+        ref = O.solve_batch(np.array([st.state7()]), np.zeros((1, 2)), np.array([pl.K.kparams]), np.array([0], np.uint32),
+                            obs, *pl.C_inf, P, net=net, tv_sv=np.array([[preds[j][-1].s, preds[j][-1].v]]),
+                            enc=np.array([[e[i], e[j]]], dtype=np.float64))
+        assert ok == (ref['status'][0] == 0)
+        if ok:
+            assert rel_err(x, ref['x'][0]).max() < 1e-9
+
+
+def test_nan_inputs_and_determinism():
+    import igtmpc
+    from igtmpc.scenarios import make_batch
+    b = make_batch(64, dtype=np.float32)
+    bad = {k: (v.copy() if hasattr(v, 'copy') else v) for k, v in b.items()}
+    bad['x0'][3, 2] = np.nan          # NaN arc length
+    bad['x0'][5, 5] = np.inf          # infinite speed
+    with igtmpc.BatchSolver(dtype='f32') as s:
+        o1 = s.solve(b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy'])
+        o2 = s.solve(b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy'])
+        ob = s.solve(bad['x0'], bad['u_prev'], bad['kparams'], bad['flags'], bad['obs_xy'])
+    for k in o1:
+        assert np.array_equal(o1[k], o2[k], equal_nan=True)       # run-to-run bitwise reproducible
+    assert ob['status'][3] == 1 and ob['status'][5] == 1            # non-finite problems are reported, not propagated
+    keep = np.ones(64, bool)
+    keep[[3, 5]] = False
+    for k in o1:
+        assert np.array_equal(ob[k][keep], o1[k][keep], equal_nan=True)

@@ -154,3 +154,15 @@ def test_c_abi_exports_every_declared_symbol():
     names = re.findall(r'\b(?:int32_t|double)\s+([^;]+);', fields)
     flat = [n.strip() for grp in names for n in grp.split(',')]
     assert flat == [f[0] for f in L.igt_params._fields_]
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No CPU fallback: without libigtmpc.so the product raises ImportError naming the build command."""
+    from igtmpc import _lib as L
+    monkeypatch.setattr(L, '_lib', None)
+    monkeypatch.setattr(L, 'LIB_PATH', str(tmp_path / 'libigtmpc.so'))
+    with pytest.raises(ImportError, match='build'):
+        L.load()
+    import igtmpc
+    with pytest.raises(ImportError):
+        igtmpc.BatchSolver()
