@@ -198,12 +198,15 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     }
 
     // workspace (grows on first use, never shrinks): per-slice partial arg-min [+ value-net records]
-    const size_t W = value ? (size_t)p.C / 64 : ((size_t)p.C + 127) / 128;
+    // per-scenario partials: float value path reduces to ONE per scenario (compact list + atomicMin),
+    // double value path keeps one per 64-candidate chunk, progress cost one per 128-candidate slice
+    const bool compact = value && sizeof(T) == 4;
+    const size_t W = compact ? 1 : (value ? (size_t)p.C / 64 : ((size_t)p.C + 127) / 128);
     double *d_cpar = nullptr, *d_uprev = nullptr;
     {
         const size_t n_rec = value ? (size_t)B * p.C : 0;
-        const size_t need = (size_t)B * W * 12 + (size_t)B * 48 + n_rec * (2 * sizeof(T) + 12) +
-                            (value ? (size_t)B * igt::VN_H * sizeof(T) : 0) + 12 * 256;
+        const size_t need = (size_t)B * W * 12 + (size_t)B * 56 + n_rec * (2 * sizeof(T) + 16) +
+                            (value ? (size_t)B * igt::VN_H * sizeof(T) : 0) + 16 * 256;
         if (int rc = ensure_work(h, need, st)) return rc;
         Arena wa{(char*)h->d_work, 0};
         A.part_J = wa.take<double>((size_t)B * W);
@@ -216,6 +219,9 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
             A.rec_vN = wa.take<T>(n_rec);
             A.rec_viol = wa.take<uint32_t>(n_rec);
             A.p_vec = wa.take<T>((size_t)B * igt::VN_H);
+            A.rec_b = wa.take<int32_t>(n_rec);
+            A.rec_count = wa.take<unsigned>(64);
+            A.best_key = wa.take<unsigned long long>((size_t)B);
         }
     }
     if (h->prof) HIPCHK(hipEventRecord(h->ev[0], st));
@@ -224,6 +230,10 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
         kp.refine_it = it;
         A.cpar = it == 0 ? nullptr : d_cpar;
         if (value) {
+            if (compact) {
+                HIPCHK(hipMemsetAsync(A.rec_count, 0, 256, st));
+                HIPCHK(hipMemsetAsync(A.best_key, 0xff, (size_t)B * 8, st));
+            }
             HIPCHK(igt::launch_search_records<T>(kp, B, A, st));
             HIPCHK(igt::launch_value<T>(kp, B, net_of<T>(h), A, nullptr, nullptr, st));
             if (sizeof(T) == 8) HIPCHK(igt::launch_reduce<T>(B, (int)W, A, st));

@@ -23,6 +23,7 @@
 //   * cost terms and verdicts are formed in float from the double step-boundary state and summed
 //     in double; controls are generated in double (u_out is the oracle's candidate to rounding).
 #pragma once
+#include <type_traits>
 #include "igt_device.h"
 
 namespace igt {
@@ -247,7 +248,7 @@ struct FastPair {
 // CAND = CAND_LATTICE / CAND_RAMP_HOLD: both candidates share the steering profile (c and c+64 have the same j)
 // and satisfy the input box / rate limits by construction; CAND_TABLE: controls come from the table and are checked.
 // BOOK = false (emit): cost and verdicts are skipped, only the trajectory is produced.
-template <int CAND, bool HI_ORDER, bool BOOK, bool UNIFORM, typename T, class Sink>
+template <int CAND, bool HI_ORDER, bool BOOK, bool UNIFORM, typename T, class Sink, bool EARLY_EXIT = false>
 __device__ __forceinline__ void rollout_pair(const KP& P, const Scenario<T>& S, const int (&cidx)[2],
                                              const double* __restrict__ table,
                                              const double* __restrict__ cinf, Sink& sink, double (&Jout)[2],
@@ -258,6 +259,7 @@ __device__ __forceinline__ void rollout_pair(const KP& P, const Scenario<T>& S, 
     fp.init(P, S.b0, S.b1, S.kv);
     double s[2], ey[2], ep[2], v[2], x[2], y[2], psi[2], J[2], a_d[2], df_d[2], da[2], ddf = 0.0;
     unsigned viol[2];
+    bool dead = false;     // EARLY_EXIT: the whole slice is already infeasible
     const float ey_lim = (float)P.ey_lim, tol = (float)P.tol, vmin = (float)P.v_min, vmax = (float)P.v_max;
     const float w_u = (float)P.w_u, dmin2 = (float)P.dmin2, ratio2 = fp.lr_ratio * fp.lr_ratio;
 #pragma unroll
@@ -351,6 +353,10 @@ __device__ __forceinline__ void rollout_pair(const KP& P, const Scenario<T>& S, 
             w.d0[q] = (float)(s[q] - fp.b0);
             w.d1[q] = (float)(s[q] - fp.b1);
         }
+        if (BOOK && UNIFORM && EARLY_EXIT) {
+            // search only: once every candidate of the slice has failed a verdict, nothing rolled further can win
+            if (__all((viol[0] != 0) & (viol[1] != 0))) { dead = true; break; }
+        }
         if (BOOK && k >= 1) {                                          // collision, mpc.py:223-226
             for (int o = 0; o < P.n_obs; ++o) {
                 const double ox = (double)S.obs[(o * 2 + 0) * (P.N + 1) + k];
@@ -384,6 +390,10 @@ __device__ __forceinline__ void rollout_pair(const KP& P, const Scenario<T>& S, 
             const double nxt[7] = {x[q], y[q], s[q], ey[q], ep[q], v[q], psi[q]};
             sink.state(q, k + 1, nxt);
         }
+    }
+    if (dead) {            // costs are meaningless; the verdict bits that ended the roll are what is reported
+        Jout[0] = Jout[1] = 0.0; vout[0] = viol[0]; vout[1] = viol[1]; sN[0] = sN[1] = 0.0; vN[0] = vN[1] = 0.0;
+        return;
     }
 #pragma unroll
     for (int q = 0; q < 2 && BOOK; ++q) {

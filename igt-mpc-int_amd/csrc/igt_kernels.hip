@@ -276,7 +276,8 @@ __global__ __launch_bounds__(64) void search_fast_kernel(KP P, int B, int W, con
                                                           const double* __restrict__ cinf, const double* __restrict__ cpar,
                                                           double* __restrict__ part_J, int32_t* __restrict__ part_c,
                                                           float* __restrict__ rec_sN, float* __restrict__ rec_vN,
-                                                          double* __restrict__ rec_J, uint32_t* __restrict__ rec_viol) {
+                                                          double* __restrict__ rec_J, uint32_t* __restrict__ rec_viol,
+                                                          unsigned* __restrict__ rec_count, int32_t* __restrict__ rec_b) {
     // one wave per workgroup: waves retire and are replaced independently (no intra-workgroup coupling
     // of fast straight-route waves to slow in-arc ones)
     const int gw = blockIdx.x;
@@ -291,12 +292,24 @@ __global__ __launch_bounds__(64) void search_fast_kernel(KP P, int B, int W, con
     const int cidx[2] = {(2 * p) * 64 + lane, (2 * p + 1 < chunks ? 2 * p + 1 : 2 * p) * 64 + lane};
     double J[2], sN[2], vN[2];
     unsigned viol[2];
-    rollout_pair<CAND, HI, true, true, float>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
-    if (VALUE) {   // terminal value network: leave the terminal term to value_kernel (mpc.py:369)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const size_t idx = (size_t)b * P.C + cidx[q];
-            rec_sN[idx] = (float)sN[q]; rec_vN[idx] = (float)vN[q]; rec_J[idx] = J[q]; rec_viol[idx] = viol[q];
+    rollout_pair<CAND, HI, true, true, float, NullSink, true>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
+    if (VALUE) {   // terminal value network (mpc.py:369): append the feasible candidates for the value kernels
+        const bool dup = cidx[1] == cidx[0];                       // odd chunk count: second half is a duplicate
+        const bool ok0 = viol[0] == 0 && finite_d(J[0]), ok1 = viol[1] == 0 && finite_d(J[1]) && !dup;
+        const unsigned long long m0 = __ballot(ok0), m1 = __ballot(ok1);
+        const unsigned n0 = __popcll(m0), n1 = __popcll(m1);
+        unsigned base = 0;
+        if (lane == 0 && n0 + n1) base = atomicAdd(rec_count, n0 + n1);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int32_t* rec_c = reinterpret_cast<int32_t*>(rec_viol);
+        if (ok0) {
+            const unsigned e = base + __popcll(m0 & lt);
+            rec_b[e] = b; rec_c[e] = cidx[0]; rec_sN[e] = (float)sN[0]; rec_vN[e] = (float)vN[0]; rec_J[e] = J[0];
+        }
+        if (ok1) {
+            const unsigned e = base + n0 + __popcll(m1 & lt);
+            rec_b[e] = b; rec_c[e] = cidx[1]; rec_sN[e] = (float)sN[1]; rec_vN[e] = (float)vN[1]; rec_J[e] = J[1];
         }
         return;
     }
@@ -593,7 +606,7 @@ static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>&
     const int W = (P.C + 127) / 128;
     hipLaunchKernelGGL((search_fast_kernel<CAND, HI, VALUE>), dim3((size_t)B * W), dim3(64), 0, st, P, B, W, A.x0,
                        A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN, A.rec_vN,
-                       A.rec_J, A.rec_viol);
+                       A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
     return hipGetLastError();
 }
 template <bool VALUE>
@@ -647,6 +660,18 @@ hipError_t launch_value<double>(const KP& P, int B, const DevNet<double>& net, c
 template <>
 hipError_t launch_value<float>(const KP& P, int B, const DevNet<float>& net, const SolveArgs<float>& A, float* cost_all,
                                uint32_t* viol_all, hipStream_t st) {
+    if (!cost_all) {   // solve path: walk the compact list of feasible candidates
+        CompactRecs R{A.rec_count, A.rec_b, reinterpret_cast<const int32_t*>(A.rec_viol), A.rec_sN, A.rec_vN, A.rec_J};
+        const dim3 grid(4096), block(64);      // grid-stride over the list; 16 waves per CU
+        if (net.n_hidden_mats > 1)
+            hipLaunchKernelGGL(value_compact_h3, grid, block, 0, st, net, R, A.tv_sv, A.enc, A.best_key);
+        else
+            hipLaunchKernelGGL(value_compact_h2, grid, block, 0, st, net, R, A.tv_sv, A.enc, A.best_key);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(keys_to_partials_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, A.best_key, A.part_J, A.part_c);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((value_prep_kernel<float>), dim3(B), dim3(VN_H), 0, st, B, net, A.tv_sv, A.enc, A.p_vec);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

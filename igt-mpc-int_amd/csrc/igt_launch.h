@@ -32,6 +32,10 @@ struct SolveArgs {   // all device pointers
     double* rec_J;         // [B, C] cost without the terminal term
     uint32_t* rec_viol;    // [B, C]
     T* p_vec;              // [B, 128] first-layer offsets
+    // float path: feasible candidates appended by the search pass (count, scenario, candidate in rec_viol's storage)
+    unsigned* rec_count;
+    int32_t* rec_b;
+    unsigned long long* best_key;   // [B] per-scenario (orderable cost, candidate) minimum
 };
 
 template <typename T> hipError_t launch_search(const KP& P, int B, const SolveArgs<T>& A, int nc, hipStream_t st);

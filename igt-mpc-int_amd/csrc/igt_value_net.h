@@ -253,6 +253,146 @@ __global__ __launch_bounds__(64) void value_kernel_f32_h3(int B, int C, DevNet<f
     value_finish(gw, c, idx, V, viol, net, rec_J, part_J, part_c, cost_all, viol_all);
 }
 
+// ---------------------------------------------------------------------------------------
+// Compact form used by the float solve path: only ~6 % of the lattice candidates survive the verdicts, so
+// the search pass appends the feasible ones to a list (one wave-aggregated atomic per wave; a wave's entries
+// are contiguous and belong to one scenario) and the value kernels walk that list with a grid-stride loop.
+// Layer 1 is evaluated from the six features directly (6 FMAs per neuron with scalar weights), the
+// scenario's winner is kept with one 64-bit atomicMin on (orderable float cost, candidate index).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long pack_key(float J, int c) {
+    unsigned u = __float_as_uint(J);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);          // ascending order as unsigned
+    return ((unsigned long long)u << 32) | (unsigned)c;
+}
+__device__ __forceinline__ float key_cost(unsigned long long key) {
+    unsigned u = (unsigned)(key >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+
+struct CompactRecs {           // feasible candidates appended by the search pass
+    const unsigned* count;
+    const int32_t* b;
+    const int32_t* c;
+    const float* sN;
+    const float* vN;
+    const double* J;           // cost without the terminal term
+};
+
+__device__ __forceinline__ void compact_features(const CompactRecs& R, unsigned e, bool live, const float* __restrict__ tv_sv,
+                                                 const float* __restrict__ enc, float (&g)[6], int& b, int& c, double& J) {
+    b = live ? R.b[e] : 0;
+    c = live ? R.c[e] : 0;
+    J = live ? R.J[e] : 0.0;
+    const float sN = live ? R.sN[e] : 0.0f, vN = live ? R.vN[e] : 0.0f;
+    const float s_tv = tv_sv[(size_t)b * 2 + 0], v_tv = tv_sv[(size_t)b * 2 + 1];
+    const float e_ego = enc[(size_t)b * 2 + 0], e_tv = enc[(size_t)b * 2 + 1];
+    // x_N = [s_tv, v_tv, e_tv, s_N - s_tv, v_N - v_tv, e_ego - e_tv]   (mpc.py:326-338)
+    g[0] = s_tv; g[1] = v_tv; g[2] = e_tv; g[3] = sN - s_tv; g[4] = vN - v_tv; g[5] = e_ego - e_tv;
+}
+
+__device__ __forceinline__ float layer1(const DevNet<float>& net, int i, const float (&g)[6]) {
+    float a = net.c1[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a = fmaf(net.A1[i * 6 + k], g[k], a);
+    return tanh_fast(a);
+}
+
+__device__ __forceinline__ void compact_finish(const DevNet<float>& net, bool live, int b, int c, double J, float V,
+                                               unsigned long long* __restrict__ best_key) {
+    const double Jt = J - ((double)V * (double)net.sigma_t + (double)net.mu_t);   // mpc.py:369
+    const float Jf = (float)Jt;
+    if (live && fabsf(Jf) < 3.0e38f) atomicMin(&best_key[b], pack_key(Jf, c));
+}
+
+__global__ __launch_bounds__(64) void value_compact_h2(DevNet<float> net, CompactRecs R, const float* __restrict__ tv_sv,
+                                                       const float* __restrict__ enc,
+                                                       unsigned long long* __restrict__ best_key) {
+    const unsigned count = *R.count;
+    for (unsigned base = blockIdx.x * 64u; base < count; base += gridDim.x * 64u) {
+        const unsigned e = base + threadIdx.x;
+        const bool live = e < count;
+        float g[6];
+        int b, c;
+        double J;
+        compact_features(R, e, live, tv_sv, enc, g, b, c, J);
+        float h[VN_H];
+#pragma unroll
+        for (int i = 0; i < VN_H; ++i) h[i] = layer1(net, i, g);
+        float V = net.bout;
+        const float* __restrict__ WT = net.WT[0];
+        const float* __restrict__ bias = net.bias[0];
+        for (int t = 0; t < VN_H / 16; ++t) {
+            float acc[16];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) acc[jj] = bias[t * 16 + jj];
+#pragma unroll
+            for (int i = 0; i < VN_H; ++i) {
+                const float* __restrict__ w = WT + (size_t)i * VN_H + t * 16;
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) acc[jj] = fmaf(w[jj], h[i], acc[jj]);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) V = fmaf(net.wout[t * 16 + jj], tanh_fast(acc[jj]), V);
+        }
+        compact_finish(net, live, b, c, J, V, best_key);
+    }
+}
+
+__global__ __launch_bounds__(64) void value_compact_h3(DevNet<float> net, CompactRecs R, const float* __restrict__ tv_sv,
+                                                       const float* __restrict__ enc,
+                                                       unsigned long long* __restrict__ best_key) {
+    const unsigned count = *R.count;
+    const float* __restrict__ WT0 = net.WT[0];
+    const float* __restrict__ WT1 = net.WT[1];
+    for (unsigned base = blockIdx.x * 64u; base < count; base += gridDim.x * 64u) {
+        const unsigned e = base + threadIdx.x;
+        const bool live = e < count;
+        float g[6];
+        int b, c;
+        double J;
+        compact_features(R, e, live, tv_sv, enc, g, b, c, J);
+        float acc3[VN_H];
+#pragma unroll
+        for (int j = 0; j < VN_H; ++j) acc3[j] = net.bias[1][j];
+        for (int t = 0; t < VN_H / 16; ++t) {
+            float acc2[16];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) acc2[jj] = net.bias[0][t * 16 + jj];
+#pragma unroll 4
+            for (int i = 0; i < VN_H; ++i) {
+                const float h1 = layer1(net, i, g);
+                const float* __restrict__ w = WT0 + (size_t)i * VN_H + t * 16;
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) acc2[jj] = fmaf(w[jj], h1, acc2[jj]);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const float h2 = tanh_fast(acc2[jj]);
+                const float* __restrict__ w3 = WT1 + (size_t)(t * 16 + jj) * VN_H;
+#pragma unroll
+                for (int j = 0; j < VN_H; ++j) acc3[j] = fmaf(w3[j], h2, acc3[j]);
+            }
+        }
+        float V = net.bout;
+#pragma unroll
+        for (int j = 0; j < VN_H; ++j) V = fmaf(net.wout[j], tanh_fast(acc3[j]), V);
+        compact_finish(net, live, b, c, J, V, best_key);
+    }
+}
+
+// best_key[B] -> one partial per scenario (part_J, part_c with W = 1) for refine / emit
+__global__ __launch_bounds__(256) void keys_to_partials_kernel(int B, const unsigned long long* __restrict__ best_key,
+                                                               double* __restrict__ part_J, int32_t* __restrict__ part_c) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned long long k = best_key[b];
+    const bool any = k != 0xffffffffffffffffull;
+    part_c[b] = any ? (int32_t)(unsigned)(k & 0xffffffffull) : -1;
+    part_J[b] = any ? (double)key_cost(k) : 0.0;
+}
+
 #endif  // IGT_KERNELS_TU
 
 }  // namespace igt
