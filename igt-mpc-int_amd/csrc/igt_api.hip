@@ -52,6 +52,7 @@ struct igt_handle {
     hipEvent_t ev[3];
     bool ev_recorded;
     int nc;
+    int n_cu;              // compute units of the device (sizes the persistent search grid)
 };
 
 namespace {
@@ -90,6 +91,8 @@ igt::KP make_kp(const igt_params& p, int F) {
     k.cand_mode = p.cand_mode; k.cost_mode = p.cost_mode; k.F = F;
     k.G = p.cand_mode == IGT_CAND_TABLE ? 1 : isqrt_exact(p.C);
     k.refine_it = 0;
+    k.df_small = p.df_max < 0.78 ? 1 : 0;
+    { const char* e = getenv("IGT_DEV_FLAGS"); k.dev = e ? atoi(e) : 0; }
     k.dt = p.dt;
     k.h = p.dt / p.n_rk4;                      // frenet.py:93
     k.l_r = p.l_r;
@@ -205,7 +208,7 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     double *d_cpar = nullptr, *d_uprev = nullptr;
     {
         const size_t n_rec = value ? (size_t)B * p.C : 0;
-        const size_t need = (size_t)B * W * 12 + (size_t)B * 56 + n_rec * (2 * sizeof(T) + 16) +
+        const size_t need = (size_t)B * W * 12 + (size_t)B * 56 + 4096 + n_rec * (2 * sizeof(T) + 16) +
                             (value ? (size_t)B * igt::VN_H * sizeof(T) : 0) + 16 * 256;
         if (int rc = ensure_work(h, need, st)) return rc;
         Arena wa{(char*)h->d_work, 0};
@@ -213,6 +216,12 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
         A.part_c = wa.take<int32_t>((size_t)B * W);
         d_cpar = wa.take<double>((size_t)B * 4);
         d_uprev = wa.take<double>((size_t)B * 2);
+        A.work_counter = wa.take<unsigned>(8 * 64);
+        {   // persistent search waves (batches of >= 4 units per wave slot): 3 per SIMD keep the VALU ~90 % busy
+            int per_simd = 3;
+            if (const char* e = std::getenv("IGT_DEV_SLOTS")) { const int v = std::atoi(e); if (v >= 1 && v <= 3) per_simd = v; }
+            A.wave_slots = h->n_cu * 4 * per_simd;
+        }
         if (value) {
             A.rec_J = wa.take<double>(n_rec);
             A.rec_sN = wa.take<T>(n_rec);
@@ -231,6 +240,7 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
         A.cpar = it == 0 ? nullptr : d_cpar;
         if (value) {
             if (compact) {
+                HIPCHK(hipMemsetAsync(A.work_counter, 0, 8 * 256, st));
                 HIPCHK(hipMemsetAsync(A.rec_count, 0, 256, st));
                 HIPCHK(hipMemsetAsync(A.best_key, 0xff, (size_t)B * 8, st));
             }
@@ -238,6 +248,7 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
             HIPCHK(igt::launch_value<T>(kp, B, net_of<T>(h), A, nullptr, nullptr, st));
             if (sizeof(T) == 8) HIPCHK(igt::launch_reduce<T>(B, (int)W, A, st));
         } else {
+            if (sizeof(T) == 4) HIPCHK(hipMemsetAsync(A.work_counter, 0, 8 * 256, st));
             HIPCHK(igt::launch_search<T>(kp, B, A, h->nc, st));
         }
         if (it < p.refine_iters) {   // winner of this pass -> centre / span of the next one
@@ -503,6 +514,8 @@ int igt_create(const igt_params* p, int device, igt_handle** out) {
         if (v == 1 || v == 2 || v == 4) h->nc = v;
     }
     while ((p->C / 64) % h->nc) h->nc /= 2;
+    h->n_cu = 256;
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) h->n_cu = v; }
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(IGT_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
     for (int i = 0; i < 3; ++i) {

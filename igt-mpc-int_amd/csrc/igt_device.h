@@ -19,6 +19,8 @@ namespace igt {
 
 struct KP {  // kernel parameters (by value -> SGPRs)
     int N, n_rk4, C, n_obs, cand_mode, cost_mode, F, G, hi_order, refine_it;
+    int df_small;   // df_max < pi/4: generated steering angles need no range reduction
+    int dev;   // developer switches (env IGT_DEV_FLAGS, experiments only): 1 = slices along the acceleration axis, 2 = no early exit, 8 / 32 = never / always persistent search waves, 16 = slice-major static order
     double dt, h, l_r, lr_ratio, v_min, v_max, a_min, a_max, df_max;
     double rate_a, rate_df, ey_lim, dmin2, w_u, tol;
 };
@@ -230,6 +232,7 @@ struct Scenario {           // wave-uniform inputs of one scenario
 };
 
 struct NullSink {
+    static constexpr bool kKeepsStates = false;
     __device__ __forceinline__ void ctrl(int, int, double, double) {}
     __device__ __forceinline__ void state(int, int, const double (&)[7]) {}
 };

@@ -90,6 +90,21 @@ __device__ __forceinline__ void sincos_reduced(double ang, float& s, float& c) {
     c = ((q + 1) & 2) ? -b : b;
 }
 
+// the same polynomials for an angle already known to lie in (-pi/4, pi/4): sincos_reduced() has kd = 0 there
+// and r = (float)ang, so the two agree bit for bit
+__device__ __forceinline__ void sincos_quadrant0(float r, float& s, float& c) {
+    const float r2 = r * r;
+    float ps = fmaf(r2, 2.7557319e-6f, -1.9841270e-4f);
+    ps = fmaf(r2, ps, 8.3333333e-3f);
+    ps = fmaf(r2, ps, -1.6666667e-1f);
+    s = fmaf(r * r2, ps, r);
+    float pc = fmaf(r2, 2.4801587e-5f, -1.3888889e-3f);
+    pc = fmaf(r2, pc, 4.1666667e-2f);
+    pc = fmaf(r2, pc, -0.5f);
+    c = fmaf(r2, pc, 1.0f);
+}
+constexpr float QUADRANT0 = 0.78f;     // < pi/4
+
 template <bool HI_ORDER>
 struct FastPair {
     // per-scenario constants
@@ -231,6 +246,15 @@ struct FastPair {
             for (int j = 0; j < n_rk4; ++j) substep<true>(a, ha, sblr, w);
             return;
         }
+        {   // the whole control step stays clear of both break-points: |travel| <= 1.5 dt (|v| + dt |a|)
+            const f2 m = splat(1.5f * (float)dt) * (__builtin_elementwise_abs(w.v1) + splat((float)dt) * __builtin_elementwise_abs(a));
+            const f2 lo = w.d0 + m, hi = w.d1 - m;
+            const bool clear = ((lo.x < 0.0f) | (hi.x > 0.0f)) & ((lo.y < 0.0f) | (hi.y > 0.0f));
+            if (__all(clear)) {
+                for (int j = 0; j < n_rk4; ++j) substep<true>(a, ha, sblr, w);
+                return;
+            }
+        }
         for (int j = 0; j < n_rk4; ++j) {
             // travel bound of this sub-step: |o| <= h |ds| <= 1.5 h (|v| + |h a|)
             const f2 m = splat(1.5f * h) * (__builtin_elementwise_abs(w.v1) + splat(2.0f) * __builtin_elementwise_abs(ha));
@@ -284,6 +308,7 @@ __device__ __forceinline__ void rollout_pair(const KP& P, const Scenario<T>& S, 
     float sp0, cp0;
     sincos_reduced(S.x0[6], sp0, cp0);
     typename FP::Work w;
+    w.d0 = w.d1 = splat(0.0f);
     w.s2 = splat(sp0); w.c2 = splat(cp0);      // carried as (sin,cos)(psi + beta_k); beta_{-1} = 0
     f2 cb_prev = splat(1.0f), sb_prev = splat(0.0f);
 
@@ -322,7 +347,8 @@ __device__ __forceinline__ void rollout_pair(const KP& P, const Scenario<T>& S, 
                 // beta = atan(r tan df), r = l_r/(l_f+l_r):  cos(beta) = c/n, sin(beta) = r s/n,
                 // n = sqrt(c^2 + r^2 s^2), (s,c) = (sin,cos)(df)   (|df| < pi/2)
                 float sdf, cdf;
-                sincos_reduced(df_d[q], sdf, cdf);
+                if (CAND != CAND_TABLE && P.df_small) sincos_quadrant0((float)df_d[q], sdf, cdf);   // |df| <= df_max < pi/4
+                else sincos_reduced(df_d[q], sdf, cdf);
                 const float n = __builtin_amdgcn_rsqf(fmaf(ratio2 * sdf, sdf, cdf * cdf));   // argument in [r^2, 1]
                 cb[q] = cdf * n;
                 sb[q] = fp.lr_ratio * sdf * n;
@@ -335,27 +361,34 @@ __device__ __forceinline__ void rollout_pair(const KP& P, const Scenario<T>& S, 
         const f2 sblr = sb * splat(fp.inv_lr);
         tu = splat(w_u) * fma2(a, a, tu);                              // mpc.py:362
         // ---- bookkeeping of state k + float working set of this control step
+        const float epf[2] = {(float)ep[0], (float)ep[1]};
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             w.ey[q] = (float)ey[q];
             w.v1[q] = (float)v[q];
             if (BOOK) {
-                const float epf = (float)ep[q];
-                const float t = fmaf(w.ey[q], w.ey[q], fmaf(epf, epf, tu[q]));    // mpc.py:362-364
+                const float t = fmaf(w.ey[q], w.ey[q], fmaf(epf[q], epf[q], tu[q]));    // mpc.py:362-364
                 J[q] += (double)t;
                 if (fabsf(w.ey[q]) - ey_lim > tol) viol[q] |= VIOL_EY;          // mpc.py:296-299
                 if (fmaxf(vmin - w.v1[q], w.v1[q] - vmax) > tol) viol[q] |= VIOL_BOX_V;   // mpc.py:316-317 (k < N)
                 if (k == P.N - 1) viol[q] |= terminal_viol(P, v[q], a_d[q], cinf);       // mpc.py:177-180
             }
-            float se, ce;
-            sincos_reduced(ep[q], se, ce);
-            w.s1[q] = se; w.c1[q] = ce;
-            w.d0[q] = (float)(s[q] - fp.b0);
-            w.d1[q] = (float)(s[q] - fp.b1);
+            if (fp.kv != 0.0f) {               // break-point-relative arc length (unused on straight routes)
+                w.d0[q] = (float)(s[q] - fp.b0);
+                w.d1[q] = (float)(s[q] - fp.b1);
+            }
+        }
+        // (sin,cos)(epsi): heading errors beyond pi/4 are rare, so the range reduction is skipped when no lane needs it
+        if (__all((fabsf(epf[0]) < QUADRANT0) & (fabsf(epf[1]) < QUADRANT0))) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { float se, ce; sincos_quadrant0(epf[q], se, ce); w.s1[q] = se; w.c1[q] = ce; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { float se, ce; sincos_reduced(ep[q], se, ce); w.s1[q] = se; w.c1[q] = ce; }
         }
         if (BOOK && UNIFORM && EARLY_EXIT) {
             // search only: once every candidate of the slice has failed a verdict, nothing rolled further can win
-            if (__all((viol[0] != 0) & (viol[1] != 0))) { dead = true; break; }
+            if (__all((viol[0] != 0) & (viol[1] != 0)) && !(P.dev & 2)) { dead = true; break; }
         }
         if (BOOK && k >= 1) {                                          // collision, mpc.py:223-226
             for (int o = 0; o < P.n_obs; ++o) {
@@ -385,7 +418,8 @@ __device__ __forceinline__ void rollout_pair(const KP& P, const Scenario<T>& S, 
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             s[q] += (double)w.acc_s[q]; ey[q] += (double)w.acc_ey[q]; ep[q] += (double)w.acc_ep[q];
-            x[q] += (double)w.acc_x[q]; y[q] += (double)w.acc_y[q]; psi[q] += (double)w.acc_psi[q];
+            x[q] += (double)w.acc_x[q]; y[q] += (double)w.acc_y[q];
+            if (Sink::kKeepsStates) psi[q] += (double)w.acc_psi[q];      // psi feeds nothing back (search: dead)
             v[q] = fma(fp.dt, a_d[q], v[q]);
             const double nxt[7] = {x[q], y[q], s[q], ey[q], ep[q], v[q], psi[q]};
             sink.state(q, k + 1, nxt);

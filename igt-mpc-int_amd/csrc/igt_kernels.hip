@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void to_double_kernel(size_t n, const T* __res
 
 template <typename T>
 struct StoreSink {
+    static constexpr bool kKeepsStates = true;
     T* x;   // [7, N+1] of this scenario/candidate (may be null)
     T* u;   // [2, N]
     int N;
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(256) void rollout_all_kernel(KP P, int B, const T* 
 // ---------------------------------------------------------------------------------------
 template <typename T>
 struct PairSink {
+    static constexpr bool kKeepsStates = true;
     T* x[2];
     T* u[2];
     int N;
@@ -263,33 +265,38 @@ struct PairSink {
     }
 };
 
-// One wave = one (scenario, 128-candidate slice): W = ceil(C/128) waves per scenario, so a B = 4096 batch is
-// 8192 independent waves (better balance over the 2048 wave slots than 4096 double-length ones).  Each wave
-// stores its slice's best (J, c); emit_fast_kernel reduces the W partials (ties -> lowest candidate index).
+// One work unit = one (scenario, 128-candidate slice): W = ceil(C/128) units per scenario.  A unit is rolled by
+// one 64-lane wave and leaves its slice's best (J, c); emit_fast_kernel reduces the W partials (ties -> lowest
+// candidate index).
 template <int CAND, bool HI, bool VALUE>
-__global__ __launch_bounds__(64) void search_fast_kernel(KP P, int B, int W, const float* __restrict__ x0,
-                                                          const float* __restrict__ u_prev,
-                                                          const float* __restrict__ kparams,
-                                                          const uint32_t* __restrict__ flags,
-                                                          const float* __restrict__ obs,
-                                                          const double* __restrict__ table,
-                                                          const double* __restrict__ cinf, const double* __restrict__ cpar,
-                                                          double* __restrict__ part_J, int32_t* __restrict__ part_c,
-                                                          float* __restrict__ rec_sN, float* __restrict__ rec_vN,
-                                                          double* __restrict__ rec_J, uint32_t* __restrict__ rec_viol,
-                                                          unsigned* __restrict__ rec_count, int32_t* __restrict__ rec_b) {
-    // one wave per workgroup: waves retire and are replaced independently (no intra-workgroup coupling
-    // of fast straight-route waves to slow in-arc ones)
-    const int gw = blockIdx.x;
-    if (gw >= B * W) return;
-    const int b = gw / W, p = gw - b * W;
+__device__ __forceinline__ void search_unit(const KP& P, int W, int b, int p, const float* __restrict__ x0,
+                                            const float* __restrict__ u_prev, const float* __restrict__ kparams,
+                                            const uint32_t* __restrict__ flags, const float* __restrict__ obs,
+                                            const double* __restrict__ table, const double* __restrict__ cinf,
+                                            const double* __restrict__ cpar, double* __restrict__ part_J,
+                                            int32_t* __restrict__ part_c, float* __restrict__ rec_sN,
+                                            float* __restrict__ rec_vN, double* __restrict__ rec_J,
+                                            uint32_t* __restrict__ rec_viol, unsigned* __restrict__ rec_count,
+                                            int32_t* __restrict__ rec_b) {
+    const int gw = b * W + p;
     const int lane = threadIdx.x & 63;
     Scenario<float> S;
     load_scenario<float>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
     NullSink sink;
     const int chunks = P.C / 64;
     // an odd number of 64-candidate chunks: the last slice rolls its chunk twice (harmless duplicate)
-    const int cidx[2] = {(2 * p) * 64 + lane, (2 * p + 1 < chunks ? 2 * p + 1 : 2 * p) * 64 + lane};
+    int cidx[2] = {(2 * p) * 64 + lane, (2 * p + 1 < chunks ? 2 * p + 1 : 2 * p) * 64 + lane};
+    if (CAND != CAND_TABLE && P.G * P.G == P.C && W * 128 == P.C && P.G % W == 0 && !(P.dev & 1)) {
+        // Generated G x G families: a slice takes G/W STEERING values (all G accelerations), the values handed
+        // out from the centre of the range outwards.  The |e_y| verdict (87 % of all failures) depends mostly
+        // on the steering sequence, so the slices holding the extreme steering values fail as a whole within a
+        // few steps and leave through the early exit (tools/death_steps.py: 23 % fewer wave-steps than slices
+        // cut along the acceleration axis).  Pairs still share their steering column: (i, j) and (i + G/2, j).
+        const int nj = P.G / W, jl = lane % nj, il = lane / nj, r = p * nj + jl;
+        const int j = (r & 1) ? P.G / 2 - 1 - (r >> 1) : P.G / 2 + (r >> 1);
+        cidx[0] = il * P.G + j;
+        cidx[1] = (il + P.G / 2) * P.G + j;
+    }
     double J[2], sN[2], vN[2];
     unsigned viol[2];
     rollout_pair<CAND, HI, true, true, float, NullSink, true>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
@@ -329,6 +336,51 @@ __global__ __launch_bounds__(64) void search_fast_kernel(KP P, int B, int W, con
         if (take) { bestJ = oJ; bestC = oC; }
     }
     if (lane == 0) { part_J[gw] = bestJ; part_c[gw] = bestC; }
+}
+
+// Two ways of handing the units to waves (one wave per workgroup, 168 VGPRs => 3 per SIMD):
+//   * queues == 0: workgroup n rolls unit n (scenario n / W, slice n mod W) -- the hardware dispatcher does the
+//     balancing.  Replacing a retired workgroup costs tens of microseconds of idle wave slot on this part
+//     (measured: 2 of 3 slots occupied on average), so this is only used for small batches;
+//   * queues == 8: persistent waves.  Unit durations differ 3x (early exit, straight vs arc), so the waves take
+//     units from counters until none is left.  A returning device-scope atomic on ONE address retires every
+//     ~11.4 ns on MI355X (tools/atomic_probe.hip; the XCDs' L2s are not coherent, so it executes memory-side):
+//     a single counter would cap the kernel at 44 M solves/s and queue the waves of a small batch behind each
+//     other.  Hence one counter per XCD (workgroup n runs on XCD n mod 8), 256 B apart; queue q owns the
+//     scenarios b = q (mod 8) and deals them out scenario-major (centre slice, then extreme slice).  No
+//     stealing: every queue holds B/8 random scenarios, the imbalance between XCDs is ~1-2 %.  The next index is
+//     fetched while the current unit is rolled.
+template <int CAND, bool HI, bool VALUE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void search_fast_kernel(
+    KP P, int B, int W, int queues, unsigned* __restrict__ work_counter, const float* __restrict__ x0,
+    const float* __restrict__ u_prev, const float* __restrict__ kparams, const uint32_t* __restrict__ flags,
+    const float* __restrict__ obs, const double* __restrict__ table, const double* __restrict__ cinf,
+    const double* __restrict__ cpar, double* __restrict__ part_J, int32_t* __restrict__ part_c,
+    float* __restrict__ rec_sN, float* __restrict__ rec_vN, double* __restrict__ rec_J,
+    uint32_t* __restrict__ rec_viol, unsigned* __restrict__ rec_count, int32_t* __restrict__ rec_b) {
+    if (queues == 0) {
+        const int n = blockIdx.x, b = n / W;
+        search_unit<CAND, HI, VALUE>(P, W, b, n - b * W, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J,
+                                     part_c, rec_sN, rec_vN, rec_J, rec_viol, rec_count, rec_b);
+        return;
+    }
+    const unsigned q = blockIdx.x % (unsigned)queues, uW = (unsigned)W;
+    const unsigned n_scen = ((unsigned)B + (unsigned)queues - 1u - q) / (unsigned)queues;   // scenarios b = q mod queues
+    const unsigned K = n_scen * uW;
+    unsigned* counter = work_counter + q * 64u;
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    unsigned k = 0;
+    if (lane0) k = atomicAdd(counter, 1u);
+    k = __builtin_amdgcn_readfirstlane(k);
+    while (k < K) {                           // every wave gets there: the counter only grows
+        unsigned nxt = 0;
+        if (lane0) nxt = atomicAdd(counter, 1u);
+        const unsigned j = k / uW;
+        search_unit<CAND, HI, VALUE>(P, W, (int)(q + (unsigned)queues * j), (int)(k - j * uW), x0, u_prev, kparams, flags,
+                                     obs, table, cinf, cpar, part_J, part_c, rec_sN, rec_vN, rec_J, rec_viol, rec_count,
+                                     rec_b);
+        k = __builtin_amdgcn_readfirstlane(nxt);
+    }
 }
 
 template <int CAND, bool HI>
@@ -604,7 +656,11 @@ static hipError_t launch_search_exact(const KP& P, int B, const SolveArgs<double
 template <int CAND, bool HI, bool VALUE>
 static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>& A, hipStream_t st) {
     const int W = (P.C + 127) / 128;
-    hipLaunchKernelGGL((search_fast_kernel<CAND, HI, VALUE>), dim3((size_t)B * W), dim3(64), 0, st, P, B, W, A.x0,
+    const size_t total = (size_t)B * W;
+    // small batches: one unit per workgroup; big ones: persistent waves on per-XCD queues (see the kernel)
+    const bool persistent = (P.dev & 8) ? false : (P.dev & 32) ? true : total >= (size_t)A.wave_slots * 10;
+    const size_t grid = persistent ? (size_t)A.wave_slots : total;
+    hipLaunchKernelGGL((search_fast_kernel<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, persistent ? 8 : 0, A.work_counter, A.x0,
                        A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN, A.rec_vN,
                        A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
     return hipGetLastError();
