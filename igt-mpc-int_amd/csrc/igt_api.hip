@@ -217,11 +217,7 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
         d_cpar = wa.take<double>((size_t)B * 4);
         d_uprev = wa.take<double>((size_t)B * 2);
         A.work_counter = wa.take<unsigned>(8 * 64);
-        {   // persistent search waves (batches of >= 4 units per wave slot): 3 per SIMD keep the VALU ~90 % busy
-            int per_simd = 3;
-            if (const char* e = std::getenv("IGT_DEV_SLOTS")) { const int v = std::atoi(e); if (v >= 1 && v <= 3) per_simd = v; }
-            A.wave_slots = h->n_cu * 4 * per_simd;
-        }
+        A.n_cu = h->n_cu;
         if (value) {
             A.rec_J = wa.take<double>(n_rec);
             A.rec_sN = wa.take<T>(n_rec);

@@ -20,7 +20,7 @@ namespace igt {
 struct KP {  // kernel parameters (by value -> SGPRs)
     int N, n_rk4, C, n_obs, cand_mode, cost_mode, F, G, hi_order, refine_it;
     int df_small;   // df_max < pi/4: generated steering angles need no range reduction
-    int dev;   // developer switches (env IGT_DEV_FLAGS, experiments only): 1 = slices along the acceleration axis, 2 = no early exit, 8 / 32 = never / always persistent search waves, 16 = slice-major static order
+    int dev;   // developer switches (env IGT_DEV_FLAGS, experiments only): 1 = slices along the acceleration axis, 2 = no early exit, 8 / 32 = force 2 / 3 search waves per SIMD
     double dt, h, l_r, lr_ratio, v_min, v_max, a_min, a_max, df_max;
     double rate_a, rate_df, ey_lim, dmin2, w_u, tol;
 };

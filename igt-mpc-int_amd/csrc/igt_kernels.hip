@@ -338,32 +338,23 @@ __device__ __forceinline__ void search_unit(const KP& P, int W, int b, int p, co
     if (lane == 0) { part_J[gw] = bestJ; part_c[gw] = bestC; }
 }
 
-// Two ways of handing the units to waves (one wave per workgroup, 168 VGPRs => 3 per SIMD):
-//   * queues == 0: workgroup n rolls unit n (scenario n / W, slice n mod W) -- the hardware dispatcher does the
-//     balancing.  Replacing a retired workgroup costs tens of microseconds of idle wave slot on this part
-//     (measured: 2 of 3 slots occupied on average), so this is only used for small batches;
-//   * queues == 8: persistent waves.  Unit durations differ 3x (early exit, straight vs arc), so the waves take
-//     units from counters until none is left.  A returning device-scope atomic on ONE address retires every
-//     ~11.4 ns on MI355X (tools/atomic_probe.hip; the XCDs' L2s are not coherent, so it executes memory-side):
-//     a single counter would cap the kernel at 44 M solves/s and queue the waves of a small batch behind each
-//     other.  Hence one counter per XCD (workgroup n runs on XCD n mod 8), 256 B apart; queue q owns the
-//     scenarios b = q (mod 8) and deals them out scenario-major (centre slice, then extreme slice).  No
-//     stealing: every queue holds B/8 random scenarios, the imbalance between XCDs is ~1-2 %.  The next index is
-//     fetched while the current unit is rolled.
+// Persistent waves, one per workgroup.  Replacing a retired single-unit workgroup costs tens of microseconds of idle
+// wave slot on this part (measured: 2 of 3 slots occupied on average) and unit durations differ 3x (early exit,
+// straight vs arc), so the waves loop, taking units from counters until none is left.  A returning device-scope
+// atomic on ONE address retires every ~11.4 ns on MI355X (tools/atomic_probe.hip; the XCDs' L2s are not coherent,
+// so it executes memory-side): a single counter would cap the kernel at 44 M solves/s and queue the waves of a
+// small batch behind each other.  Hence one counter per XCD (workgroup n runs on XCD n mod 8), 256 B apart; queue q
+// owns the scenarios b = q (mod 8) and deals them out scenario-major (centre slice, then extreme slice).  No
+// stealing: every queue holds B/8 random scenarios, the imbalance between XCDs is ~1-2 %.  The next index is fetched
+// while the current unit is rolled.
 template <int CAND, bool HI, bool VALUE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void search_fast_kernel(
-    KP P, int B, int W, int queues, unsigned* __restrict__ work_counter, const float* __restrict__ x0,
+__device__ __forceinline__ void search_waves(
+    const KP& P, int B, int W, int queues, unsigned* __restrict__ work_counter, const float* __restrict__ x0,
     const float* __restrict__ u_prev, const float* __restrict__ kparams, const uint32_t* __restrict__ flags,
     const float* __restrict__ obs, const double* __restrict__ table, const double* __restrict__ cinf,
     const double* __restrict__ cpar, double* __restrict__ part_J, int32_t* __restrict__ part_c,
     float* __restrict__ rec_sN, float* __restrict__ rec_vN, double* __restrict__ rec_J,
     uint32_t* __restrict__ rec_viol, unsigned* __restrict__ rec_count, int32_t* __restrict__ rec_b) {
-    if (queues == 0) {
-        const int n = blockIdx.x, b = n / W;
-        search_unit<CAND, HI, VALUE>(P, W, b, n - b * W, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J,
-                                     part_c, rec_sN, rec_vN, rec_J, rec_viol, rec_count, rec_b);
-        return;
-    }
     const unsigned q = blockIdx.x % (unsigned)queues, uW = (unsigned)W;
     const unsigned n_scen = ((unsigned)B + (unsigned)queues - 1u - q) / (unsigned)queues;   // scenarios b = q mod queues
     const unsigned K = n_scen * uW;
@@ -381,6 +372,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                                      rec_b);
         k = __builtin_amdgcn_readfirstlane(nxt);
     }
+}
+
+// The same loop built twice: 3 waves per SIMD (168 VGPRs, a 128 B/lane spill around each unit) keeps the VALU ~90 %
+// busy on big batches; 2 per SIMD (no spill) rolls a unit in less wall time, which is what bounds a small batch.
+#define IGT_SEARCH_ARGS                                                                                              \
+    KP P, int B, int W, int queues, unsigned* __restrict__ work_counter, const float* __restrict__ x0,               \
+        const float* __restrict__ u_prev, const float* __restrict__ kparams, const uint32_t* __restrict__ flags,     \
+        const float* __restrict__ obs, const double* __restrict__ table, const double* __restrict__ cinf,            \
+        const double* __restrict__ cpar, double* __restrict__ part_J, int32_t* __restrict__ part_c,                  \
+        float* __restrict__ rec_sN, float* __restrict__ rec_vN, double* __restrict__ rec_J,                          \
+        uint32_t* __restrict__ rec_viol, unsigned* __restrict__ rec_count, int32_t* __restrict__ rec_b
+#define IGT_SEARCH_PASS                                                                                              \
+    P, B, W, queues, work_counter, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN, rec_vN, \
+        rec_J, rec_viol, rec_count, rec_b
+template <int CAND, bool HI, bool VALUE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void search_fast_kernel_o3(IGT_SEARCH_ARGS) {
+    search_waves<CAND, HI, VALUE>(IGT_SEARCH_PASS);
+}
+template <int CAND, bool HI, bool VALUE>
+__global__ __launch_bounds__(64) void search_fast_kernel_o2(IGT_SEARCH_ARGS) {
+    search_waves<CAND, HI, VALUE>(IGT_SEARCH_PASS);
 }
 
 template <int CAND, bool HI>
@@ -657,12 +669,19 @@ template <int CAND, bool HI, bool VALUE>
 static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>& A, hipStream_t st) {
     const int W = (P.C + 127) / 128;
     const size_t total = (size_t)B * W;
-    // small batches: one unit per workgroup; big ones: persistent waves on per-XCD queues (see the kernel)
-    const bool persistent = (P.dev & 8) ? false : (P.dev & 32) ? true : total >= (size_t)A.wave_slots * 10;
-    const size_t grid = persistent ? (size_t)A.wave_slots : total;
-    hipLaunchKernelGGL((search_fast_kernel<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, persistent ? 8 : 0, A.work_counter, A.x0,
-                       A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN, A.rec_vN,
-                       A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
+    // persistent waves on per-XCD queues; 3 per SIMD once there are >= 10 units per wave slot, else 2 per SIMD
+    const bool big = total >= (size_t)A.n_cu * 12 * 10;
+    const bool o3 = (P.dev & 8) ? false : (P.dev & 32) ? true : big;
+    const size_t slots = (size_t)A.n_cu * 4 * (o3 ? 3 : 2);
+    const size_t grid = total < slots ? total : slots;
+    if (o3)
+        hipLaunchKernelGGL((search_fast_kernel_o3<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
+                           A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN,
+                           A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
+    else
+        hipLaunchKernelGGL((search_fast_kernel_o2<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
+                           A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN,
+                           A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
     return hipGetLastError();
 }
 template <bool VALUE>

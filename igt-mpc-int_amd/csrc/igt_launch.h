@@ -34,7 +34,7 @@ struct SolveArgs {   // all device pointers
     T* p_vec;              // [B, 128] first-layer offsets
     // float path: feasible candidates appended by the search pass (count, scenario, candidate in rec_viol's storage)
     unsigned* work_counter;         // search_fast_kernel's 8 unit counters, 256 B apart (zeroed before every launch)
-    int wave_slots;                 // resident waves the search kernel is sized for (CUs x 4 SIMDs x 3)
+    int n_cu;                       // compute units (sizes the persistent search grid)
     unsigned* rec_count;
     int32_t* rec_b;
     unsigned long long* best_key;   // [B] per-scenario (orderable cost, candidate) minimum

@@ -37,7 +37,36 @@ def main(root):
             v = dd['ns'][len(dd['ns']) // 4:]
             out['counters_mean_per_launch'][f'{fam}.dur_ns.{tag}'] = sum(v) / len(v)
     for f in glob.glob(os.path.join(root, 'stats', '**', '*kernel_stats.csv'), recursive=True):
-        out['stats'] = [r for r in csv.DictReader(open(f))][:12]
+        out['stats'] = [{k: (v[:90] if k == 'Name' else v) for k, v in r.items()} for r in csv.DictReader(open(f))][:6]
+    c = out['counters_mean_per_launch']
+    g = lambda k: c.get(k)
+    B = int(os.environ.get('IGT_PMC_BATCH', '4096'))
+    out['batch'] = B
+    # HBM bytes per launch, MI355X_MICROARCH.md HBM section: (FETCH_SIZE + WRITE_SIZE) * 1024, separate passes.  The
+    # guide's x2 FETCH_SIZE correction is for 16 B/lane coalesced vector streams; the search kernel reads its inputs
+    # with scalar (SMEM) loads, so the raw counter is reported.
+    for fam, key in (('search_fast', 'search'), ('emit_fast', 'emit')):
+        f, w = g(f'{fam}.FETCH_SIZE.pmc1'), g(f'{fam}.WRITE_SIZE.pmc2')
+        if f is not None and w is not None:
+            out[f'{key}_kernel_hbm_bytes_per_launch'] = (f + w) * 1024.0
+    out['algorithmic_bytes_per_launch'] = {'search': (220 + 12) * B, 'emit': 972 * B}
+    d = {}
+    if g('search_fast.GRBM_GUI_ACTIVE.pmc4') and g('search_fast.dur_ns.pmc4'):
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        d['shader_clock_GHz_during_search'] = g('search_fast.GRBM_GUI_ACTIVE.pmc4') / 8.0 / g('search_fast.dur_ns.pmc4')
+    if g('search_fast.SQ_WAVES.pmc3'):
+        waves = g('search_fast.SQ_WAVES.pmc3')
+        d['waves_per_launch'] = waves
+        d['valu_instructions_per_launch'] = g('search_fast.SQ_INSTS_VALU.pmc3')
+        d['valu_instructions_per_unit'] = g('search_fast.SQ_INSTS_VALU.pmc3') / (2.0 * B)
+        clk = d.get('shader_clock_GHz_during_search', 2.23)
+        simd_cycles = 1024.0 * g('search_fast.dur_ns.pmc3') * clk
+        d['simd_valu_busy_fraction'] = 4.0 * g('search_fast.SQ_ACTIVE_INST_VALU.pmc3') / simd_cycles     # SQ_* are quad-cycles
+        d['mean_waves_resident_per_simd'] = 4.0 * g('search_fast.SQ_WAVE_CYCLES.pmc3') / simd_cycles
+        wc = g('search_fast.SQ_WAVE_CYCLES.pmc3')
+        d['wave_cycles_split'] = {'active': g('search_fast.SQ_ACTIVE_INST_ANY.pmc3') / wc,
+                                  'issue_stall': g('search_fast.SQ_WAIT_INST_ANY.pmc3') / wc}
+    out['derived'] = d
     json.dump(out, sys.stdout, indent=1)
 
 if __name__ == '__main__':
