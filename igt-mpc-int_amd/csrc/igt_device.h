@@ -219,6 +219,30 @@ __device__ __forceinline__ unsigned terminal_viol(const KP& P, double v, double 
     return (P.F > 0 && worst > P.tol) ? (unsigned)VIOL_TERMINAL : 0u;
 }
 
+// the same test for two candidates at once, four facets per trip: the facets arrive by scalar loads whose latency
+// (not the 6 flops per facet) is what one wave pays, so they are issued in batches and shared by both candidates
+__device__ __forceinline__ void terminal_viol2(const KP& P, const double (&v)[2], const double (&a)[2],
+                                               const double* __restrict__ cinf, unsigned (&viol)[2]) {
+    double w0 = -1e300, w1 = -1e300;
+    int m = 0;
+    for (; m + 4 <= P.F; m += 4) {
+        double A0[4], A1[4], bb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { A0[i] = cinf[(m + i) * 3 + 0]; A1[i] = cinf[(m + i) * 3 + 1]; bb[i] = cinf[(m + i) * 3 + 2]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            w0 = fmax(w0, A0[i] * v[0] + A1[i] * a[0] - bb[i]);
+            w1 = fmax(w1, A0[i] * v[1] + A1[i] * a[1] - bb[i]);
+        }
+    }
+    for (; m < P.F; ++m) {
+        w0 = fmax(w0, cinf[m * 3 + 0] * v[0] + cinf[m * 3 + 1] * a[0] - cinf[m * 3 + 2]);
+        w1 = fmax(w1, cinf[m * 3 + 0] * v[1] + cinf[m * 3 + 1] * a[1] - cinf[m * 3 + 2]);
+    }
+    if (P.F > 0 && w0 > P.tol) viol[0] |= VIOL_TERMINAL;
+    if (P.F > 0 && w1 > P.tol) viol[1] |= VIOL_TERMINAL;
+}
+
 // ---------------------------------------------------------------------------------------
 // one rollout pass over NC candidates of one scenario
 // ---------------------------------------------------------------------------------------

@@ -166,14 +166,18 @@ struct FastPair {
         f2 sd2, cd2, sd3, cd3;
         ssc_half(HH * w1, sd2, cd2);
         ssc_half(HH * w2, sd3, cd3);
-        f2 As, Bs, Ae, Be, ip, sdC, cdC;
+        // psi advances by h w2 per sub-step in closed form (w is linear in v: w1 + 4 w2 + w4 = 6 w2); epsi advances by the
+        // same amount minus the curvature term  corr = h/6 (K1 ds1 + 2 K2 ds2 + 2 K3 ds3 + K4 ds4), which is exactly 0
+        // on the K == 0 branch -- there both base pairs are rotated by (sin,cos)(h w2) and nothing else.
+        f2 As, Bs, Ae, Be, ip, sdC, cdC, sdP, cdP, corr = splat(0.0f);
         if (K0) {
             // K == 0 at every stage argument of every lane: 1 - K ey = 1 and depsi = dpsi, so the
             // (beta+epsi) stage offsets are the psi offsets and the gains are the speeds.
-            ssc(H * w2, sdC, cdC);
+            ssc(H * w2, sdP, cdP);
+            sdC = sdP; cdC = cdP;
             stage_sums(v1, v2, v2, v4, sd2, cd2, sd3, cd3, sdC, cdC, Ae, Be);
             As = Ae; Bs = Be;
-            ip = H6 * (w1 + TWO * w2 + TWO * w2 + w4);
+            ip = H * w2;
         } else {
             const f2 e0 = fma2(w.d0, BIG, ONE), e1 = fma2(w.d1, BIG, ONE);
             const f2 ey = w.ey;
@@ -183,7 +187,8 @@ struct FastPair {
             const f2 g1 = v1 * rcp2(fma2(-K, ey, ONE));
             const f2 ds1 = g1 * c1;
             const f2 de1 = v1 * s1;
-            const f2 dp1 = fma2(-ds1, K, w1);
+            const f2 kd1 = ds1 * K;
+            const f2 dp1 = w1 - kd1;
             // ---- stage 2: arguments base + h/2 k1
             ssc_half(HH * dp1, sdA, cdA);
             sa = s1; ca = c1; rotate2(sa, ca, sdA, cdA);
@@ -191,7 +196,8 @@ struct FastPair {
             const f2 g2 = v2 * rcp2(fma2(-K, fma2(HH, de1, ey), ONE));
             const f2 ds2 = g2 * ca;
             const f2 de2 = v2 * sa;
-            const f2 dp2 = fma2(-ds2, K, w2);
+            const f2 kd2 = ds2 * K;
+            const f2 dp2 = w2 - kd2;
             // ---- stage 3: base + h/2 k2
             ssc_half(HH * dp2, sdB, cdB);
             sa = s1; ca = c1; rotate2(sa, ca, sdB, cdB);
@@ -199,16 +205,19 @@ struct FastPair {
             const f2 g3 = v2 * rcp2(fma2(-K, fma2(HH, de2, ey), ONE));
             const f2 ds3 = g3 * ca;
             const f2 de3 = v2 * sa;
-            const f2 dp3 = fma2(-ds3, K, w2);
+            const f2 kd3 = ds3 * K;
+            const f2 dp3 = w2 - kd3;
             // ---- stage 4: base + h k3 (only its cosine is needed individually, for depsi)
             ssc(H * dp3, sdC, cdC);
             K = curv(e0, e1, H * ds3);
             const f2 g4 = v4 * rcp2(fma2(-K, fma2(H, de3, ey), ONE));
             const f2 ds4 = g4 * fma2(c1, cdC, -(s1 * sdC));
-            const f2 dp4 = fma2(-ds4, K, w4);
+            const f2 kd4 = ds4 * K;
             stage_sums(g1, g2, g3, g4, sdA, cdA, sdB, cdB, sdC, cdC, As, Bs);
             stage_sums(v1, v2, v2, v4, sdA, cdA, sdB, cdB, sdC, cdC, Ae, Be);
-            ip = H6 * (dp1 + TWO * dp2 + TWO * dp3 + dp4);
+            ssc(H * w2, sdP, cdP);
+            corr = H6 * (kd1 + TWO * kd2 + TWO * kd3 + kd4);
+            ip = H * w2 - corr;
         }
         // ---- Frenet increments (frenet.py:113-115)
         const f2 is = H6 * fma2(c1, As, -(s1 * Bs));
@@ -223,12 +232,14 @@ struct FastPair {
         w.acc_psi = fma2(H6, w1 + splat(4.0f) * w2 + w4, w.acc_psi);
         w.acc_s += is; w.acc_ey += ie; w.acc_ep += ip;
         w.d0 += is; w.d1 += is; w.ey += ie; w.v1 = v4;
-        // ---- base pairs for the next sub-step: psi advanced by h*w2 = twice the stage-3 offset
-        f2 sd, cd;
-        ssc(ip, sd, cd);
-        rotate2(w.s1, w.c1, sd, cd);
-        const f2 s22 = TWO * sd3 * cd3, c22 = fma2(-TWO * sd3, sd3, ONE);
-        rotate2(w.s2, w.c2, s22, c22);
+        // ---- base pairs for the next sub-step: both advance by h w2, (beta+epsi) additionally by -corr
+        rotate2(w.s1, w.c1, sdP, cdP);
+        rotate2(w.s2, w.c2, sdP, cdP);
+        if (!K0) {
+            f2 sd, cd;
+            ssc(-corr, sd, cd);
+            rotate2(w.s1, w.c1, sd, cd);
+        }
     }
 
     // n_rk4 sub-steps of one control step.  The K == 0 branch is taken when it is provably exact for the
@@ -311,6 +322,7 @@ __device__ __forceinline__ void rollout_pair(const KP& P, const Scenario<T>& S, 
     w.d0 = w.d1 = splat(0.0f);
     w.s2 = splat(sp0); w.c2 = splat(cp0);      // carried as (sin,cos)(psi + beta_k); beta_{-1} = 0
     f2 cb_prev = splat(1.0f), sb_prev = splat(0.0f);
+    float ox_next = 0.0f, oy_next = 0.0f;      // obstacle 0 at the state the next trip books
 
     for (int k = 0; k < P.N; ++k) {
         // ---- controls of step k (double)
@@ -371,13 +383,13 @@ __device__ __forceinline__ void rollout_pair(const KP& P, const Scenario<T>& S, 
                 J[q] += (double)t;
                 if (fabsf(w.ey[q]) - ey_lim > tol) viol[q] |= VIOL_EY;          // mpc.py:296-299
                 if (fmaxf(vmin - w.v1[q], w.v1[q] - vmax) > tol) viol[q] |= VIOL_BOX_V;   // mpc.py:316-317 (k < N)
-                if (k == P.N - 1) viol[q] |= terminal_viol(P, v[q], a_d[q], cinf);       // mpc.py:177-180
             }
             if (fp.kv != 0.0f) {               // break-point-relative arc length (unused on straight routes)
                 w.d0[q] = (float)(s[q] - fp.b0);
                 w.d1[q] = (float)(s[q] - fp.b1);
             }
         }
+        if (BOOK && k == P.N - 1) terminal_viol2(P, v, a_d, cinf, viol);                  // mpc.py:177-180
         // (sin,cos)(epsi): heading errors beyond pi/4 are rare, so the range reduction is skipped when no lane needs it
         if (__all((fabsf(epf[0]) < QUADRANT0) & (fabsf(epf[1]) < QUADRANT0))) {
 #pragma unroll
@@ -390,10 +402,14 @@ __device__ __forceinline__ void rollout_pair(const KP& P, const Scenario<T>& S, 
             // search only: once every candidate of the slice has failed a verdict, nothing rolled further can win
             if (__all((viol[0] != 0) & (viol[1] != 0)) && !(P.dev & 2)) { dead = true; break; }
         }
-        if (BOOK && k >= 1) {                                          // collision, mpc.py:223-226
-            for (int o = 0; o < P.n_obs; ++o) {
-                const double ox = (double)S.obs[(o * 2 + 0) * (P.N + 1) + k];
-                const double oy = (double)S.obs[(o * 2 + 1) * (P.N + 1) + k];
+        if (BOOK) {                                                    // collision, mpc.py:223-226 (k >= 1)
+            // obstacle 0 of the NEXT state is requested now and used one trip later: a scalar load's latency is
+            // longer than the bookkeeping between here and the sub-steps, and few waves share a SIMD
+            const float ox0 = ox_next, oy0 = oy_next;
+            if (P.n_obs > 0) { ox_next = S.obs[k + 1]; oy_next = S.obs[(P.N + 1) + k + 1]; }
+            for (int o = 0; o < P.n_obs && k >= 1; ++o) {
+                const double ox = o == 0 ? (double)ox0 : (double)S.obs[(o * 2 + 0) * (P.N + 1) + k];
+                const double oy = o == 0 ? (double)oy0 : (double)S.obs[(o * 2 + 1) * (P.N + 1) + k];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const float dx = (float)(x[q] - ox), dy = (float)(y[q] - oy);
@@ -435,8 +451,8 @@ __device__ __forceinline__ void rollout_pair(const KP& P, const Scenario<T>& S, 
         J[q] += (double)fmaf(eyq, eyq, epf * epf);
         if (fabsf(eyq) - ey_lim > tol) viol[q] |= VIOL_EY;
         for (int o = 0; o < P.n_obs; ++o) {
-            const float dx = (float)(x[q] - (double)S.obs[(o * 2 + 0) * (P.N + 1) + P.N]);
-            const float dy = (float)(y[q] - (double)S.obs[(o * 2 + 1) * (P.N + 1) + P.N]);
+            const float dx = (float)(x[q] - (o == 0 ? (double)ox_next : (double)S.obs[(o * 2 + 0) * (P.N + 1) + P.N]));
+            const float dy = (float)(y[q] - (o == 0 ? (double)oy_next : (double)S.obs[(o * 2 + 1) * (P.N + 1) + P.N]));
             if (dmin2 - fmaf(dx, dx, dy * dy) > tol) viol[q] |= VIOL_COLLISION;
         }
         if (!(fabs(x[q]) < 1e300 && fabs(y[q]) < 1e300 && fabs(s[q]) < 1e300 && fabs(ey[q]) < 1e300 &&
