@@ -154,8 +154,11 @@ struct FastPair {
         B = fma2(g4, sdC, fma2(t3, sdB, t2 * sdA));
     }
 
-    template <bool K0>
+    // MODE 0: general (K decided per stage argument); 1: K == 0 at every stage argument of every lane; 2: every stage
+    // argument of every lane lies strictly inside the arc, K == kv.  All three give identical bits where they apply.
+    template <int MODE>
     __device__ __forceinline__ void substep(f2 a, f2 ha, f2 sblr, Work& w) const {
+        constexpr bool K0 = MODE == 1, KC = MODE == 2;
         const f2 H = splat(h), HH = splat(hh), H6 = splat(h6), BIG = splat(big), ONE = splat(1.0f), TWO = splat(2.0f);
         const f2 v1 = w.v1;
         const f2 v2 = v1 + ha;            // stages 2,3
@@ -183,7 +186,7 @@ struct FastPair {
             const f2 ey = w.ey;
             f2 sdA, cdA, sdB, cdB, sa, ca;
             // ---- stage 1
-            f2 K = (clamp01(e0) - clamp01(e1)) * splat(kv);
+            f2 K = KC ? splat(kv) : (clamp01(e0) - clamp01(e1)) * splat(kv);
             const f2 g1 = v1 * rcp2(fma2(-K, ey, ONE));
             const f2 ds1 = g1 * c1;
             const f2 de1 = v1 * s1;
@@ -192,7 +195,7 @@ struct FastPair {
             // ---- stage 2: arguments base + h/2 k1
             ssc_half(HH * dp1, sdA, cdA);
             sa = s1; ca = c1; rotate2(sa, ca, sdA, cdA);
-            K = curv(e0, e1, HH * ds1);
+            if (!KC) K = curv(e0, e1, HH * ds1);
             const f2 g2 = v2 * rcp2(fma2(-K, fma2(HH, de1, ey), ONE));
             const f2 ds2 = g2 * ca;
             const f2 de2 = v2 * sa;
@@ -201,7 +204,7 @@ struct FastPair {
             // ---- stage 3: base + h/2 k2
             ssc_half(HH * dp2, sdB, cdB);
             sa = s1; ca = c1; rotate2(sa, ca, sdB, cdB);
-            K = curv(e0, e1, HH * ds2);
+            if (!KC) K = curv(e0, e1, HH * ds2);
             const f2 g3 = v2 * rcp2(fma2(-K, fma2(HH, de2, ey), ONE));
             const f2 ds3 = g3 * ca;
             const f2 de3 = v2 * sa;
@@ -209,7 +212,7 @@ struct FastPair {
             const f2 dp3 = w2 - kd3;
             // ---- stage 4: base + h k3 (only its cosine is needed individually, for depsi)
             ssc(H * dp3, sdC, cdC);
-            K = curv(e0, e1, H * ds3);
+            if (!KC) K = curv(e0, e1, H * ds3);
             const f2 g4 = v4 * rcp2(fma2(-K, fma2(H, de3, ey), ONE));
             const f2 ds4 = g4 * fma2(c1, cdC, -(s1 * sdC));
             const f2 kd4 = ds4 * K;
@@ -242,37 +245,44 @@ struct FastPair {
         }
     }
 
-    // n_rk4 sub-steps of one control step.  The K == 0 branch is taken when it is provably exact for the
-    // whole wave (straight route, or every lane's stage arguments stay on one side of both break-points).
-    // UNIFORM = false (one lane per scenario, emit): lanes disagree, so only the general branch is used
-    // (bit-identical values either way).
+    // n_rk4 sub-steps of one control step.  The K == 0 branch (or the K == kv one) is taken when it is provably
+    // exact for every active lane of the wave: straight route, or every lane's stage arguments stay outside (inside)
+    // the arc [b0, b1] by the travel bound |ds| <= 2 |v| (1/(1 - K ey) < 2 for any state near the road).
+    // The lanes of a wave may belong to different scenarios (emit uses UNIFORM = false: general branch only).
     template <bool UNIFORM>
     __device__ __forceinline__ void substeps(f2 a, f2 sblr, Work& w) const {
         const f2 ha = splat(hh) * a;
         if (!UNIFORM) {
-            for (int j = 0; j < n_rk4; ++j) substep<false>(a, ha, sblr, w);
+            for (int j = 0; j < n_rk4; ++j) substep<0>(a, ha, sblr, w);
             return;
         }
         if (kv == 0.0f) {                      // straight route: scalar condition, hoisted
-            for (int j = 0; j < n_rk4; ++j) substep<true>(a, ha, sblr, w);
+            for (int j = 0; j < n_rk4; ++j) substep<1>(a, ha, sblr, w);
             return;
         }
-        {   // the whole control step stays clear of both break-points: |travel| <= 1.5 dt (|v| + dt |a|)
-            const f2 m = splat(1.5f * (float)dt) * (__builtin_elementwise_abs(w.v1) + splat((float)dt) * __builtin_elementwise_abs(a));
-            const f2 lo = w.d0 + m, hi = w.d1 - m;
+        {   // the whole control step: |travel| <= 2 dt (|v| + dt |a|)
+            const f2 m = splat(2.0f * (float)dt) * (__builtin_elementwise_abs(w.v1) + splat((float)dt) * __builtin_elementwise_abs(a));
+            const f2 lo = w.d0 + m, hi = w.d1 - m, in0 = w.d0 - m, in1 = w.d1 + m;
             const bool clear = ((lo.x < 0.0f) | (hi.x > 0.0f)) & ((lo.y < 0.0f) | (hi.y > 0.0f));
+            const bool inside = (in0.x > 0.0f) & (in1.x < 0.0f) & (in0.y > 0.0f) & (in1.y < 0.0f);
             if (__all(clear)) {
-                for (int j = 0; j < n_rk4; ++j) substep<true>(a, ha, sblr, w);
+                for (int j = 0; j < n_rk4; ++j) substep<1>(a, ha, sblr, w);
+                return;
+            }
+            if (__all(inside)) {
+                for (int j = 0; j < n_rk4; ++j) substep<2>(a, ha, sblr, w);
                 return;
             }
         }
         for (int j = 0; j < n_rk4; ++j) {
-            // travel bound of this sub-step: |o| <= h |ds| <= 1.5 h (|v| + |h a|)
-            const f2 m = splat(1.5f * h) * (__builtin_elementwise_abs(w.v1) + splat(2.0f) * __builtin_elementwise_abs(ha));
-            const f2 lo = w.d0 + m, hi = w.d1 - m;
+            // travel bound of this sub-step: |o| <= h |ds| <= 2 h (|v| + |h a|)
+            const f2 m = splat(2.0f * h) * (__builtin_elementwise_abs(w.v1) + splat(2.0f) * __builtin_elementwise_abs(ha));
+            const f2 lo = w.d0 + m, hi = w.d1 - m, in0 = w.d0 - m, in1 = w.d1 + m;
             const bool clear = ((lo.x < 0.0f) | (hi.x > 0.0f)) & ((lo.y < 0.0f) | (hi.y > 0.0f));
-            if (__all(clear)) substep<true>(a, ha, sblr, w);
-            else substep<false>(a, ha, sblr, w);
+            const bool inside = (in0.x > 0.0f) & (in1.x < 0.0f) & (in0.y > 0.0f) & (in1.y < 0.0f);
+            if (__all(clear)) substep<1>(a, ha, sblr, w);
+            else if (__all(inside)) substep<2>(a, ha, sblr, w);
+            else substep<0>(a, ha, sblr, w);
         }
     }
 };
