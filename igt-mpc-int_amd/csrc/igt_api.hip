@@ -624,16 +624,41 @@ int igt_set_value_net(igt_handle* h, int32_t n_layers, const int32_t* dims, cons
     }
     const size_t offWo = (size_t)(q - blk.data());
     for (int j = 0; j < H; ++j) q[j] = Wo[j];
-    std::vector<float> blkf(n);
+    // float block = the plain arrays followed by the MFMA fragment block (igt_value_net.h, value_mfma_kernel)
+    const size_t nfrag = (size_t)igt::frag_floats(nm);
+    std::vector<float> blkf(n + nfrag);
     for (size_t i = 0; i < n; ++i) blkf[i] = (float)blk[i];
+    {
+        float* f = blkf.data() + n;
+        for (int t = 0; t < 4; ++t)                       // A1F: [A1 | c1 | 0] in A-operand order
+            for (int s4 = 0; s4 < 4; ++s4)
+                for (int l = 0; l < 64; ++l) {
+                    const int i = 32 * t + (l & 31), k = 2 * s4 + (l >> 5);
+                    *f++ = (float)(k < 6 ? A1[i * 6 + k] : (k == 6 ? c1[i] : 0.0));
+                }
+        for (int m = 0; m < nm; ++m)                      // WF[m]: W[j][i], i in the accumulator's row order
+            for (int t = 0; t < 4; ++t)
+                for (int ks = 0; ks < 64; ++ks)
+                    for (int l = 0; l < 64; ++l) {
+                        const int j = 32 * t + (l & 31), i = 32 * (ks >> 4) + igt::frag_row(ks & 15, l >> 5);
+                        *f++ = (float)Wh[m][(size_t)j * H + i];
+                    }
+        for (int m = 0; m < nm; ++m)                      // BF[m]
+            for (int t = 0; t < 4; ++t)
+                for (int r = 0; r < 16; ++r)
+                    for (int hh = 0; hh < 2; ++hh) *f++ = (float)bh[m][32 * t + igt::frag_row(r, hh)];
+        for (int t = 0; t < 4; ++t)                       // WOF
+            for (int r = 0; r < 16; ++r)
+                for (int hh = 0; hh < 2; ++hh) *f++ = (float)Wo[32 * t + igt::frag_row(r, hh)];
+    }
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->d_net) { HIPCHK(hipFree(h->d_net)); h->d_net = nullptr; }
-    const size_t bytes_f = ((n * 4 + 255) / 256) * 256;
+    const size_t bytes_f = (((n + nfrag) * 4 + 255) / 256) * 256;
     HIPCHK(hipMalloc(&h->d_net, bytes_f + n * 8));
     float* df = reinterpret_cast<float*>(h->d_net);
     double* dd = reinterpret_cast<double*>(reinterpret_cast<char*>(h->d_net) + bytes_f);
-    HIPCHK(hipMemcpy(df, blkf.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(df, blkf.data(), (n + nfrag) * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dd, blk.data(), n * 8, hipMemcpyHostToDevice));
     auto fill = [&](auto& net, auto* base) {
         net.A1 = base; net.c1 = base + (size_t)H * 6;
@@ -643,6 +668,8 @@ int igt_set_value_net(igt_handle* h, int32_t n_layers, const int32_t* dims, cons
     };
     fill(h->net_f, df);
     fill(h->net_d, dd);
+    h->net_f.frag = df + n;
+    h->net_d.frag = nullptr;
     h->net_f.bout = (float)bo; h->net_f.sigma_t = (float)sigma_t; h->net_f.mu_t = (float)mu_t;
     h->net_d.bout = bo; h->net_d.sigma_t = sigma_t; h->net_d.mu_t = mu_t;
     h->net_set = true;

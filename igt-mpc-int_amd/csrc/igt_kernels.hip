@@ -737,12 +737,21 @@ hipError_t launch_value<float>(const KP& P, int B, const DevNet<float>& net, con
                                uint32_t* viol_all, hipStream_t st) {
     if (!cost_all) {   // solve path: walk the compact list of feasible candidates
         CompactRecs R{A.rec_count, A.rec_b, reinterpret_cast<const int32_t*>(A.rec_viol), A.rec_sN, A.rec_vN, A.rec_J};
-        const dim3 grid(4096), block(64);      // grid-stride over the list; 16 waves per CU
-        if (net.n_hidden_mats > 1)
-            hipLaunchKernelGGL(value_compact_h3, grid, block, 0, st, net, R, A.tv_sv, A.enc, A.best_key);
-        else
-            hipLaunchKernelGGL(value_compact_h2, grid, block, 0, st, net, R, A.tv_sv, A.enc, A.best_key);
-        hipError_t e = hipGetLastError();
+        // one 8-wave workgroup per CU (the weight fragments take 68 / 134 KB of its LDS), grid-stride over the list
+        const size_t lds = (size_t)frag_floats(net.n_hidden_mats) * sizeof(float);
+        hipError_t e;
+        if (net.n_hidden_mats > 1) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_mfma_kernel<2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(value_mfma_kernel<2>, dim3(A.n_cu), dim3(512), lds, st, net, R, A.tv_sv, A.enc, A.best_key);
+        } else {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_mfma_kernel<1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(value_mfma_kernel<1>, dim3(A.n_cu), dim3(512), lds, st, net, R, A.tv_sv, A.enc, A.best_key);
+        }
+        e = hipGetLastError();
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(keys_to_partials_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, A.best_key, A.part_J, A.part_c);
         return hipGetLastError();

@@ -27,7 +27,13 @@ struct DevNet {                // device pointers, all wave-uniform
     const T* wout;             // [128]
     T bout, sigma_t, mu_t;
     int n_hidden_mats;         // 1 (two hidden layers) or 2 (three hidden layers)
+    const float* frag;         // MFMA fragment block (float nets only; see value_mfma_kernel)
 };
+
+// MFMA fragment block of the float net (layout: value_mfma_kernel)
+constexpr int FRAG_A1 = 4 * 4 * 64, FRAG_W = 4 * 64 * 64, FRAG_B = 4 * 16 * 2;
+__host__ __device__ constexpr int frag_floats(int nm) { return FRAG_A1 + nm * FRAG_W + nm * FRAG_B + FRAG_B; }
+__host__ __device__ constexpr int frag_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }   // C/D row of register r
 
 template <typename T> __device__ __forceinline__ T tanh_t(T x);
 template <> __device__ __forceinline__ float tanh_t<float>(float x) { return tanhf(x); }
@@ -306,79 +312,96 @@ __device__ __forceinline__ void compact_finish(const DevNet<float>& net, bool li
     if (live && fabsf(Jf) < 3.0e38f) atomicMin(&best_key[b], pack_key(Jf, c));
 }
 
-__global__ __launch_bounds__(64) void value_compact_h2(DevNet<float> net, CompactRecs R, const float* __restrict__ tv_sv,
-                                                       const float* __restrict__ enc,
-                                                       unsigned long long* __restrict__ best_key) {
-    const unsigned count = *R.count;
-    for (unsigned base = blockIdx.x * 64u; base < count; base += gridDim.x * 64u) {
-        const unsigned e = base + threadIdx.x;
-        const bool live = e < count;
-        float g[6];
-        int b, c;
-        double J;
-        compact_features(R, e, live, tv_sv, enc, g, b, c, J);
-        float h[VN_H];
-#pragma unroll
-        for (int i = 0; i < VN_H; ++i) h[i] = layer1(net, i, g);
-        float V = net.bout;
-        const float* __restrict__ WT = net.WT[0];
-        const float* __restrict__ bias = net.bias[0];
-        for (int t = 0; t < VN_H / 16; ++t) {
-            float acc[16];
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj) acc[jj] = bias[t * 16 + jj];
-#pragma unroll
-            for (int i = 0; i < VN_H; ++i) {
-                const float* __restrict__ w = WT + (size_t)i * VN_H + t * 16;
-#pragma unroll
-                for (int jj = 0; jj < 16; ++jj) acc[jj] = fmaf(w[jj], h[i], acc[jj]);
-            }
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj) V = fmaf(net.wout[t * 16 + jj], tanh_fast(acc[jj]), V);
-        }
-        compact_finish(net, live, b, c, J, V, best_key);
-    }
-}
+// ---------------------------------------------------------------------------------------
+// The network over the compact list on the matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate).
+// This part of the path IS a dense contraction: [128 x 128] x [128 x 10^6 feasible candidates] per hidden layer.
+// Everything is kept transposed, X = [neuron x candidate]: a layer is Y = W X, summed over X's ROW index, so a
+// layer's accumulator tiles (column = candidate on the lane, 16 rows in the registers) are the next layer's B
+// operands as they stand -- no LDS round trip, no shuffles.  The k order this implies (k-step (ti, r) pairs row
+// 32 ti + (r&3) + 8 (r>>2) of lane half 0 with the same + 4 of lane half 1) is baked into the A fragments, which
+// igt_set_value_net lays out once (frag block below) and every workgroup stages into LDS (68 / 134 KB).
+//   wave = 32 candidates (lanes l and l+32 hold the same candidate, different rows)
+//   layer 1:  [128 x 8] x [8 x 32], features (f0..f5, 1, 0): the bias rides as the 7th feature      16 MFMA
+//   hidden :  4 output tiles x 64 k-steps, accumulators start at the bias fragment                  256 MFMA each
+//   output :  64 FMAs per lane + one cross-half add
+// frag block (floats): A1F[4][4][64] | WF[m][4][64][64] (m < n_hidden_mats) | BF[m][4][16][2] | WOF[4][16][2]
+// ---------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(64) void value_compact_h3(DevNet<float> net, CompactRecs R, const float* __restrict__ tv_sv,
-                                                       const float* __restrict__ enc,
-                                                       unsigned long long* __restrict__ best_key) {
+template <int NM>
+__global__ __launch_bounds__(512) void value_mfma_kernel(DevNet<float> net, CompactRecs R, const float* __restrict__ tv_sv,
+                                                         const float* __restrict__ enc,
+                                                         unsigned long long* __restrict__ best_key) {
+    extern __shared__ float lds[];
+    constexpr int NF = frag_floats(NM);
+    for (int i = threadIdx.x; i < NF; i += 512) lds[i] = net.frag[i];
+    __syncthreads();
+    const float* A1F = lds;
+    const float* WF = lds + FRAG_A1;
+    const float* BF = WF + NM * FRAG_W;
+    const float* WOF = BF + NM * FRAG_B;
+    const int lane = threadIdx.x & 63, half = lane >> 5;
     const unsigned count = *R.count;
-    const float* __restrict__ WT0 = net.WT[0];
-    const float* __restrict__ WT1 = net.WT[1];
-    for (unsigned base = blockIdx.x * 64u; base < count; base += gridDim.x * 64u) {
-        const unsigned e = base + threadIdx.x;
+    const unsigned wave = blockIdx.x * 8u + (threadIdx.x >> 6), nwaves = gridDim.x * 8u;
+    for (unsigned base = wave * 32u; base < count; base += nwaves * 32u) {
+        const unsigned e = base + (unsigned)(lane & 31);
         const bool live = e < count;
         float g[6];
         int b, c;
         double J;
         compact_features(R, e, live, tv_sv, enc, g, b, c, J);
-        float acc3[VN_H];
+        // B operand of layer 1: feature k = 2 s + half
+        const float xs[4] = {half ? g[1] : g[0], half ? g[3] : g[2], half ? g[5] : g[4], half ? 0.0f : 1.0f};
+        f32x16 Ha[4], Hb[4];
 #pragma unroll
-        for (int j = 0; j < VN_H; ++j) acc3[j] = net.bias[1][j];
-        for (int t = 0; t < VN_H / 16; ++t) {
-            float acc2[16];
+        for (int t = 0; t < 4; ++t) {
+            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) acc2[jj] = net.bias[0][t * 16 + jj];
-#pragma unroll 4
-            for (int i = 0; i < VN_H; ++i) {
-                const float h1 = layer1(net, i, g);
-                const float* __restrict__ w = WT0 + (size_t)i * VN_H + t * 16;
+            for (int s4 = 0; s4 < 4; ++s4)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A1F[(t * 4 + s4) * 64 + lane], xs[s4], acc, 0, 0, 0);
 #pragma unroll
-                for (int jj = 0; jj < 16; ++jj) acc2[jj] = fmaf(w[jj], h1, acc2[jj]);
-            }
+            for (int r = 0; r < 16; ++r) Ha[t][r] = tanh_fast(acc[r]);
+        }
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                const float h2 = tanh_fast(acc2[jj]);
-                const float* __restrict__ w3 = WT1 + (size_t)(t * 16 + jj) * VN_H;
+        for (int m = 0; m < NM; ++m) {
+            const float* W = WF + m * FRAG_W;
+            const float* Bm = BF + m * FRAG_B;
 #pragma unroll
-                for (int j = 0; j < VN_H; ++j) acc3[j] = fmaf(w3[j], h2, acc3[j]);
+            for (int t = 0; t < 4; ++t) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = Bm[(t * 16 + r) * 2 + half];
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) {
+                    // 16 A fragments at a time: without the fences the ILP scheduler hoists all 256 LDS reads of a
+                    // layer and spills
+                    float afr[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) afr[r] = W[(t * 64 + ti * 16 + r) * 64 + lane];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float bop = (m == 0) ? Ha[ti][r] : Hb[ti][r];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[r], bop, acc, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (m == 0) Hb[t][r] = tanh_fast(acc[r]); else Ha[t][r] = tanh_fast(acc[r]);
+                }
             }
         }
-        float V = net.bout;
+        float v = 0.0f;
 #pragma unroll
-        for (int j = 0; j < VN_H; ++j) V = fmaf(net.wout[j], tanh_fast(acc3[j]), V);
-        compact_finish(net, live, b, c, J, V, best_key);
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float hv = (NM == 1) ? Hb[t][r] : Ha[t][r];
+                v = fmaf(WOF[(t * 16 + r) * 2 + half], hv, v);
+            }
+        v += __shfl_xor(v, 32, 64);
+        compact_finish(net, live && half == 0, b, c, J, v + net.bout, best_key);
     }
 }
 
