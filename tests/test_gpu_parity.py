@@ -5,6 +5,8 @@ Bars:
   f32 entry points : 1e-5 * max(1,|ref|)   (BASELINE.json north_star), arg-min / status exact
                      on every scenario that is not decided inside float32 noise.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -237,6 +239,35 @@ def test_bad_arguments_fail_loudly(igt):
         b = _batch(4, np.float32)
         with pytest.raises(igt.IgtError):
             s.solve(*_args(b))          # table never set
+
+
+# ----------------------------------------------------------------------------- big batches: the other search variant
+@pytest.mark.parametrize('value_net', [False, True])
+def test_big_batch_variant_equals_small_batch_variant(igt, golden_dir, value_net):
+    """From 10 units per wave slot upwards (B >= 15 360 at C = 256) the solver launches the 3-waves-per-SIMD build of
+    the persistent search kernel on its per-XCD queues; below that the 2-waves-per-SIMD build.  The same scenarios,
+    solved in one ragged big batch and in small pieces, must come out bit for bit the same -- with the progress cost
+    and with the value network on the compact list (MFMA kernel, atomicMin winner)."""
+    B = 16384 + 5                                  # not a multiple of 8: the queues get unequal shares
+    b = _batch(B, np.float32)
+    kw = {}
+    extra = []
+    if value_net:
+        layers = _nets(golden_dir)[3]
+        kw = dict(cost_mode='value_net')
+        extra = [b['tv_sv'], b['enc']]
+    with igt.BatchSolver(dtype='f32', **kw) as s:
+        s.set_cinf(*_cinf())
+        if value_net:
+            s.set_value_net(layers)
+        big = s.solve(*_args(b), *extra)
+        cuts = [0, 4096, 8192, 8192 + 1003, 12288, B]
+        parts = [s.solve(*[np.ascontiguousarray(a[lo:hi]) for a in list(_args(b)) + extra]) for lo, hi in zip(cuts[:-1], cuts[1:])]
+    for k in ('x', 'u', 'argmin', 'status'):
+        assert np.array_equal(np.concatenate([q[k] for q in parts]), big[k], equal_nan=True), k
+    # the value-net winner is kept as an orderable FLOAT key: equal after rounding by construction
+    assert np.array_equal(np.concatenate([q['cost'] for q in parts]), big['cost'], equal_nan=True)
+    assert (big['status'] == 0).mean() > 0.5
 
 
 # ----------------------------------------------------------------------------- full-size properties
