@@ -430,11 +430,13 @@ __global__ __launch_bounds__(64) void emit_fast_kernel(KP P, int B, int W, const
     }
     Scenario<float> S;
     load_scenario<float>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
+    // one candidate per lane (the unpacked build of the same arithmetic: a lone roll-out is latency, and half of
+    // every packed instruction would carry a duplicate)
     PairSink<float> sink{{xo, nullptr}, {uo, nullptr}, P.N};
-    const int cidx[2] = {c, c};
-    double J[2], sN[2], vN[2];
-    unsigned viol[2];
-    rollout_pair<CAND, HI, false, false, float>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
+    const int cidx[1] = {c};
+    double J[1], sN[1], vN[1];
+    unsigned viol[1];
+    single::rollout_pair<CAND, HI, false, false, float>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
 }
 
 template <int CAND, bool HI>
