@@ -205,10 +205,11 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     // double value path keeps one per 64-candidate chunk, progress cost one per 128-candidate slice
     const bool compact = value && sizeof(T) == 4;
     const size_t W = compact ? 1 : (value ? (size_t)p.C / 64 : ((size_t)p.C + 127) / 128);
+    const size_t Wk = ((size_t)p.C + 127) / 128;          // units per scenario of the float search kernel
     double *d_cpar = nullptr, *d_uprev = nullptr;
     {
         const size_t n_rec = value ? (size_t)B * p.C : 0;
-        const size_t need = (size_t)B * W * 12 + (size_t)B * 56 + 4096 + n_rec * (2 * sizeof(T) + 16) +
+        const size_t need = (size_t)B * W * 12 + (size_t)B * 56 + 4096 + (size_t)(B + 8) * Wk * 4 + 256 + n_rec * (2 * sizeof(T) + 16) +
                             (value ? (size_t)B * igt::VN_H * sizeof(T) : 0) + 16 * 256;
         if (int rc = ensure_work(h, need, st)) return rc;
         Arena wa{(char*)h->d_work, 0};
@@ -218,6 +219,9 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
         d_uprev = wa.take<double>((size_t)B * 2);
         A.work_counter = wa.take<unsigned>(8 * 64);
         A.n_cu = h->n_cu;
+        // small batches: the search queues are sorted longest unit first (build_queues_kernel; 3-5 % up to B = 4096,
+        // nothing from 8192 on)
+        A.queue_order = (sizeof(T) == 4 && B <= 6144) ? wa.take<unsigned>((size_t)((B + 7) / 8) * 8 * Wk) : nullptr;
         if (value) {
             A.rec_J = wa.take<double>(n_rec);
             A.rec_sN = wa.take<T>(n_rec);

@@ -338,6 +338,69 @@ __device__ __forceinline__ void search_unit(const KP& P, int W, int b, int p, co
     if (lane == 0) { part_J[gw] = bestJ; part_c[gw] = bestC; }
 }
 
+// Longest units first (small batches).  A unit's wall time is what the tail of the search kernel is made of, and units
+// differ 6x: the centre-steering slice runs the whole horizon while the others mostly leave through the early exit, and
+// a scenario that meets its arc within the horizon rolls the long sub-step variants.  One workgroup per queue sorts
+// its units into four classes -- (centre, arc) > (centre, straight) > (other, arc) > (other, straight) -- keeping the
+// scenario order inside a class (a stable counting sort, so the order is a function of the inputs alone).
+// order[q][k] = (scenario ordinal in the queue) * 256 + slice.
+__global__ __launch_bounds__(256) void build_queues_kernel(KP P, int B, int W, const float* __restrict__ x0,
+                                                           const float* __restrict__ kparams,
+                                                           unsigned* __restrict__ order, int stride) {
+    __shared__ int base[4];          // running offsets of the four classes
+    __shared__ int wave_cnt[4][4];   // [wave][class] counts of the current chunk
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n_scen = (B + 8 - 1 - q) / 8, n = n_scen * W;
+    auto cls = [&](int i) {
+        const int j = i / W, p = i - j * W, b = q + 8 * j;
+        const float s0 = x0[(size_t)b * 7 + 2], v0 = x0[(size_t)b * 7 + 5];
+        const float b0 = kparams[(size_t)b * 3 + 0], b1 = kparams[(size_t)b * 3 + 1], kv = kparams[(size_t)b * 3 + 2];
+        const float reach = s0 + 1.5f * fmaxf(v0, 1.0f) * (float)(P.N * P.dt);
+        const bool arc = kv != 0.0f && reach >= b0 && s0 <= b1;
+        return (p == 0 ? 0 : 2) + (arc ? 0 : 1);
+    };
+    // pass 1: class totals -> class bases
+    int cnt[4] = {0, 0, 0, 0};
+    for (int i = tid; i < n; i += 256) cnt[cls(i)]++;
+    if (tid < 4) base[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int v = cnt[c];
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) atomicAdd(&base[c], v);      // integer sums: order of the adds does not matter
+    }
+    __syncthreads();
+    int tot[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) tot[c] = base[c];
+    __syncthreads();
+    if (tid == 0) { base[0] = 0; base[1] = tot[0]; base[2] = tot[0] + tot[1]; base[3] = tot[0] + tot[1] + tot[2]; }
+    __syncthreads();
+    // pass 2: stable scatter, 256 items per trip in index order
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        const int c = i < n ? cls(i) : -1;
+        int rank = 0;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const unsigned long long m = __ballot(c == cc);
+            if (lane == 0) wave_cnt[wv][cc] = __popcll(m);
+            if (c == cc) rank = __popcll(m & ((1ull << lane) - 1ull));
+        }
+        __syncthreads();
+        if (c >= 0) {
+            int off = base[c] + rank;
+            for (int w2 = 0; w2 < wv; ++w2) off += wave_cnt[w2][c];
+            const int j = i / W, p = i - j * W;
+            order[(size_t)q * stride + off] = (unsigned)j * 256u + (unsigned)p;
+        }
+        __syncthreads();
+        if (tid < 4) base[tid] += wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid];
+        __syncthreads();
+    }
+}
+
 // Persistent waves, one per workgroup.  Replacing a retired single-unit workgroup costs tens of microseconds of idle
 // wave slot on this part (measured: 2 of 3 slots occupied on average) and unit durations differ 3x (early exit,
 // straight vs arc), so the waves loop, taking units from counters until none is left.  A returning device-scope
@@ -349,8 +412,8 @@ __device__ __forceinline__ void search_unit(const KP& P, int W, int b, int p, co
 // while the current unit is rolled.
 template <int CAND, bool HI, bool VALUE>
 __device__ __forceinline__ void search_waves(
-    const KP& P, int B, int W, int queues, unsigned* __restrict__ work_counter, const float* __restrict__ x0,
-    const float* __restrict__ u_prev, const float* __restrict__ kparams, const uint32_t* __restrict__ flags,
+    const KP& P, int B, int W, int queues, unsigned* __restrict__ work_counter, const unsigned* __restrict__ order,
+    int order_stride, const float* __restrict__ x0, const float* __restrict__ u_prev, const float* __restrict__ kparams, const uint32_t* __restrict__ flags,
     const float* __restrict__ obs, const double* __restrict__ table, const double* __restrict__ cinf,
     const double* __restrict__ cpar, double* __restrict__ part_J, int32_t* __restrict__ part_c,
     float* __restrict__ rec_sN, float* __restrict__ rec_vN, double* __restrict__ rec_J,
@@ -360,32 +423,43 @@ __device__ __forceinline__ void search_waves(
     const unsigned K = n_scen * uW;
     unsigned* counter = work_counter + q * 64u;
     const bool lane0 = (threadIdx.x & 63) == 0;
-    unsigned k = 0;
-    if (lane0) k = atomicAdd(counter, 1u);
+    // item k of the queue: scenario ordinal j and slice p, through the longest-first order when one was built
+    const unsigned* ord = order ? order + (size_t)q * order_stride : nullptr;
+    unsigned k = 0, item = 0;
+    if (lane0) {
+        k = atomicAdd(counter, 1u);
+        item = (ord && k < K) ? ord[k] : 0u;
+    }
     k = __builtin_amdgcn_readfirstlane(k);
+    item = __builtin_amdgcn_readfirstlane(item);
     while (k < K) {                           // every wave gets there: the counter only grows
-        unsigned nxt = 0;
-        if (lane0) nxt = atomicAdd(counter, 1u);
-        const unsigned j = k / uW;
-        search_unit<CAND, HI, VALUE>(P, W, (int)(q + (unsigned)queues * j), (int)(k - j * uW), x0, u_prev, kparams, flags,
+        unsigned nxt = 0, nxt_item = 0;
+        if (lane0) {                          // fetched while the current unit is rolled
+            nxt = atomicAdd(counter, 1u);
+            nxt_item = (ord && nxt < K) ? ord[nxt] : 0u;
+        }
+        const unsigned j = ord ? item >> 8 : k / uW, p = ord ? item & 255u : k - (k / uW) * uW;
+        search_unit<CAND, HI, VALUE>(P, W, (int)(q + (unsigned)queues * j), (int)p, x0, u_prev, kparams, flags,
                                      obs, table, cinf, cpar, part_J, part_c, rec_sN, rec_vN, rec_J, rec_viol, rec_count,
                                      rec_b);
         k = __builtin_amdgcn_readfirstlane(nxt);
+        item = __builtin_amdgcn_readfirstlane(nxt_item);
     }
 }
 
 // The same loop built twice: 3 waves per SIMD (168 VGPRs, a 128 B/lane spill around each unit) keeps the VALU ~90 %
 // busy on big batches; 2 per SIMD (no spill) rolls a unit in less wall time, which is what bounds a small batch.
 #define IGT_SEARCH_ARGS                                                                                              \
-    KP P, int B, int W, int queues, unsigned* __restrict__ work_counter, const float* __restrict__ x0,               \
+    KP P, int B, int W, int queues, unsigned* __restrict__ work_counter, const unsigned* __restrict__ order,          \
+        int order_stride, const float* __restrict__ x0,                                                                 \
         const float* __restrict__ u_prev, const float* __restrict__ kparams, const uint32_t* __restrict__ flags,     \
         const float* __restrict__ obs, const double* __restrict__ table, const double* __restrict__ cinf,            \
         const double* __restrict__ cpar, double* __restrict__ part_J, int32_t* __restrict__ part_c,                  \
         float* __restrict__ rec_sN, float* __restrict__ rec_vN, double* __restrict__ rec_J,                          \
         uint32_t* __restrict__ rec_viol, unsigned* __restrict__ rec_count, int32_t* __restrict__ rec_b
 #define IGT_SEARCH_PASS                                                                                              \
-    P, B, W, queues, work_counter, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN, rec_vN, \
-        rec_J, rec_viol, rec_count, rec_b
+    P, B, W, queues, work_counter, order, order_stride, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J,    \
+        part_c, rec_sN, rec_vN, rec_J, rec_viol, rec_count, rec_b
 template <int CAND, bool HI, bool VALUE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void search_fast_kernel_o3(IGT_SEARCH_ARGS) {
     search_waves<CAND, HI, VALUE>(IGT_SEARCH_PASS);
@@ -676,13 +750,19 @@ static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>&
     const bool o3 = (P.dev & 8) ? false : (P.dev & 32) ? true : big;
     const size_t slots = (size_t)A.n_cu * 4 * (o3 ? 3 : 2);
     const size_t grid = total < slots ? total : slots;
+    const unsigned* order = nullptr;
+    const int order_stride = ((B + 7) / 8) * W;
+    if (A.queue_order && W <= 256 && !(P.dev & 16)) {        // small batches: longest units first
+        hipLaunchKernelGGL(build_queues_kernel, dim3(8), dim3(256), 0, st, P, B, W, A.x0, A.kparams, A.queue_order, order_stride);
+        order = A.queue_order;
+    }
     if (o3)
         hipLaunchKernelGGL((search_fast_kernel_o3<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
-                           A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN,
+                           order, order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN,
                            A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
     else
         hipLaunchKernelGGL((search_fast_kernel_o2<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
-                           A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN,
+                           order, order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN,
                            A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
     return hipGetLastError();
 }
