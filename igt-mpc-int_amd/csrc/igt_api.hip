@@ -209,7 +209,7 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     double *d_cpar = nullptr, *d_uprev = nullptr;
     {
         const size_t n_rec = value ? (size_t)B * p.C : 0;
-        const size_t need = (size_t)B * W * 12 + (size_t)B * 56 + 4096 + (size_t)(B + 8) * Wk * 4 + 256 + n_rec * (2 * sizeof(T) + 16) +
+        const size_t need = (size_t)B * W * 12 + (size_t)B * 56 + 8192 + (size_t)(B + 8) * Wk * 36 + 256 + n_rec * (2 * sizeof(T) + 16) +
                             (value ? (size_t)B * igt::VN_H * sizeof(T) : 0) + 16 * 256;
         if (int rc = ensure_work(h, need, st)) return rc;
         Arena wa{(char*)h->d_work, 0};
@@ -217,7 +217,8 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
         A.part_c = wa.take<int32_t>((size_t)B * W);
         d_cpar = wa.take<double>((size_t)B * 4);
         d_uprev = wa.take<double>((size_t)B * 2);
-        A.work_counter = wa.take<unsigned>(8 * 64);
+        const bool trace = (h->kp.dev & 256) != 0;      // developer trace: 32 B per unit behind the counters
+        A.work_counter = wa.take<unsigned>(1024 + (trace ? (size_t)((B + 7) / 8) * 8 * Wk * 8 : 0));
         A.n_cu = h->n_cu;
         // small batches: the search queues are sorted longest unit first (build_queues_kernel; 3-5 % up to B = 4096,
         // nothing from 8192 on)
@@ -266,6 +267,15 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     HIPCHK(igt::launch_emit<T>(kp, B, (int)W, A, st));
     if (h->prof) { HIPCHK(hipEventRecord(h->ev[2], st)); h->ev_recorded = true; }
 
+    if ((h->kp.dev & 256) && sizeof(T) == 4) {      // developer trace -> $IGT_DEV_TRACE (binary u64[units][4])
+        if (const char* path = std::getenv("IGT_DEV_TRACE")) {
+            HIPCHK(hipStreamSynchronize(st));
+            const size_t n = (size_t)((B + 7) / 8) * 8 * Wk * 4;
+            std::vector<unsigned long long> tr(n);
+            HIPCHK(hipMemcpy(tr.data(), reinterpret_cast<char*>(A.work_counter) + 4096, n * 8, hipMemcpyDeviceToHost));
+            if (FILE* f = std::fopen(path, "wb")) { std::fwrite(tr.data(), 8, n, f); std::fclose(f); }
+        }
+    }
     if (mem == IGT_MEM_HOST) {
         HIPCHK(hipMemcpyAsync(x_out, A.x_out, n_xo * sizeof(T), hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(u_out, A.u_out, n_uo * sizeof(T), hipMemcpyDeviceToHost, st));

@@ -338,6 +338,12 @@ __device__ __forceinline__ void search_unit(const KP& P, int W, int b, int p, co
     if (lane == 0) { part_J[gw] = bestJ; part_c[gw] = bestC; }
 }
 
+// Scenario j of queue q.  Blocks of 8 consecutive scenarios are dealt to the 8 queues rotated by the block index, so
+// that a batch whose make-up repeats with a period of 8 (the benchmark's does: route pair and ego index are functions
+// of b mod 64) does not give one XCD all the turning routes: measured 30 % spread between the queues' finishing times
+// with b mod 8, a few % with the rotation.  b >= B marks a hole in the last block.
+__device__ __forceinline__ int queue_scenario(int q, int j) { return 8 * j + ((q - j) & 7); }
+
 // Longest units first (small batches).  A unit's wall time is what the tail of the search kernel is made of, and units
 // differ 6x: the centre-steering slice runs the whole horizon while the others mostly leave through the early exit, and
 // a scenario that meets its arc within the horizon rolls the long sub-step variants.  One workgroup per queue sorts
@@ -350,9 +356,10 @@ __global__ __launch_bounds__(256) void build_queues_kernel(KP P, int B, int W, c
     __shared__ int base[4];          // running offsets of the four classes
     __shared__ int wave_cnt[4][4];   // [wave][class] counts of the current chunk
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n_scen = (B + 8 - 1 - q) / 8, n = n_scen * W;
+    const int n_scen = (B + 7) / 8, n = n_scen * W;
     auto cls = [&](int i) {
-        const int j = i / W, p = i - j * W, b = q + 8 * j;
+        const int j = i / W, p = i - j * W, b = queue_scenario(q, j);
+        if (b >= B) return 3;                      // a hole of the last block of 8: sorts last, skipped by the search
         const float s0 = x0[(size_t)b * 7 + 2], v0 = x0[(size_t)b * 7 + 5];
         const float b0 = kparams[(size_t)b * 3 + 0], b1 = kparams[(size_t)b * 3 + 1], kv = kparams[(size_t)b * 3 + 2];
         const float reach = s0 + 1.5f * fmaxf(v0, 1.0f) * (float)(P.N * P.dt);
@@ -407,9 +414,8 @@ __global__ __launch_bounds__(256) void build_queues_kernel(KP P, int B, int W, c
 // atomic on ONE address retires every ~11.4 ns on MI355X (tools/atomic_probe.hip; the XCDs' L2s are not coherent,
 // so it executes memory-side): a single counter would cap the kernel at 44 M solves/s and queue the waves of a
 // small batch behind each other.  Hence one counter per XCD (workgroup n runs on XCD n mod 8), 256 B apart; queue q
-// owns the scenarios b = q (mod 8) and deals them out scenario-major (centre slice, then extreme slice).  No
-// stealing: every queue holds B/8 random scenarios, the imbalance between XCDs is ~1-2 %.  The next index is fetched
-// while the current unit is rolled.
+// owns one scenario of every block of 8 (queue_scenario) and deals them out scenario-major, or longest first when
+// the batch is small (build_queues_kernel); a wave whose queue is dry takes from the other queues in turn.
 template <int CAND, bool HI, bool VALUE>
 __device__ __forceinline__ void search_waves(
     const KP& P, int B, int W, int queues, unsigned* __restrict__ work_counter, const unsigned* __restrict__ order,
@@ -419,31 +425,55 @@ __device__ __forceinline__ void search_waves(
     float* __restrict__ rec_sN, float* __restrict__ rec_vN, double* __restrict__ rec_J,
     uint32_t* __restrict__ rec_viol, unsigned* __restrict__ rec_count, int32_t* __restrict__ rec_b) {
     const unsigned q = blockIdx.x % (unsigned)queues, uW = (unsigned)W;
-    const unsigned n_scen = ((unsigned)B + (unsigned)queues - 1u - q) / (unsigned)queues;   // scenarios b = q mod queues
+    const unsigned n_scen = ((unsigned)B + 7u) / 8u;          // blocks of 8 scenarios; queue q takes one of each
     const unsigned K = n_scen * uW;
-    unsigned* counter = work_counter + q * 64u;
     const bool lane0 = (threadIdx.x & 63) == 0;
-    // item k of the queue: scenario ordinal j and slice p, through the longest-first order when one was built
-    const unsigned* ord = order ? order + (size_t)q * order_stride : nullptr;
-    unsigned k = 0, item = 0;
-    if (lane0) {
-        k = atomicAdd(counter, 1u);
-        item = (ord && k < K) ? ord[k] : 0u;
-    }
-    k = __builtin_amdgcn_readfirstlane(k);
-    item = __builtin_amdgcn_readfirstlane(item);
-    while (k < K) {                           // every wave gets there: the counter only grows
-        unsigned nxt = 0, nxt_item = 0;
-        if (lane0) {                          // fetched while the current unit is rolled
-            nxt = atomicAdd(counter, 1u);
-            nxt_item = (ord && nxt < K) ? ord[nxt] : 0u;
+    const unsigned hold = ((P.dev >> 12) & 15u ? (P.dev >> 12) & 15u : 4u) * (gridDim.x / (unsigned)queues + 1u);
+    const unsigned late_from = K > hold ? K - hold : 0u;
+    // own queue first, then the other XCDs' queues in turn (the XCDs are not equally fast: one of the eight took 10 %
+    // longer over the same work in every trace).  Item k of a queue is scenario ordinal j and slice p, through the
+    // longest-first order when one was built.
+    // The next index is fetched while the current unit is rolled -- but an index taken is an item reserved: towards the
+    // end of a queue a wave in a long unit would sit on an item that idle waves could run (measured at B = 4096: waves
+    // started leaving at 60 % of the kernel's span with items still held; units last 16 .. 130 us).  So over the last
+    // four items per wave of the queue, and when stealing, the index is fetched only when the wave is ready for it.
+    for (unsigned d = 0; d < (unsigned)queues; ++d) {
+        const unsigned qq = (q + d) % (unsigned)queues;
+        if (d > 0 && (P.dev & 512)) break;    // developer switch: no stealing
+        unsigned* counter = work_counter + qq * 64u;
+        const unsigned* ord = order ? order + (size_t)qq * order_stride : nullptr;
+        unsigned k = 0, item = 0;
+        if (lane0) {
+            k = atomicAdd(counter, 1u);
+            item = (ord && k < K) ? ord[k] : 0u;
         }
-        const unsigned j = ord ? item >> 8 : k / uW, p = ord ? item & 255u : k - (k / uW) * uW;
-        search_unit<CAND, HI, VALUE>(P, W, (int)(q + (unsigned)queues * j), (int)p, x0, u_prev, kparams, flags,
-                                     obs, table, cinf, cpar, part_J, part_c, rec_sN, rec_vN, rec_J, rec_viol, rec_count,
-                                     rec_b);
-        k = __builtin_amdgcn_readfirstlane(nxt);
-        item = __builtin_amdgcn_readfirstlane(nxt_item);
+        k = __builtin_amdgcn_readfirstlane(k);
+        item = __builtin_amdgcn_readfirstlane(item);
+        while (k < K) {                       // every wave gets there: the counters only grow
+            unsigned nxt = 0, nxt_item = 0;
+            const bool early = d == 0 && k < late_from;
+            if (early && lane0) {
+                nxt = atomicAdd(counter, 1u);
+                nxt_item = (ord && nxt < K) ? ord[nxt] : 0u;
+            }
+            const unsigned j = ord ? item >> 8 : k / uW, p = ord ? item & 255u : k - (k / uW) * uW;
+            const unsigned long long t0 = (P.dev & 256) ? wall_clock64() : 0ull;
+            const int b = queue_scenario((int)qq, (int)j);
+            if (b < B)
+                search_unit<CAND, HI, VALUE>(P, W, b, (int)p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J,
+                                             part_c, rec_sN, rec_vN, rec_J, rec_viol, rec_count, rec_b);
+            if ((P.dev & 256) && lane0) {      // developer trace (IGT_DEV_TRACE): when each unit ran, and where
+                unsigned long long* tr =
+                    reinterpret_cast<unsigned long long*>(work_counter + 1024) + ((size_t)qq * order_stride + k) * 4;
+                tr[0] = t0; tr[1] = wall_clock64(); tr[2] = blockIdx.x; tr[3] = ((unsigned long long)j << 8) | p;
+            }
+            if (!early && lane0) {
+                nxt = atomicAdd(counter, 1u);
+                nxt_item = (ord && nxt < K) ? ord[nxt] : 0u;
+            }
+            k = __builtin_amdgcn_readfirstlane(nxt);
+            item = __builtin_amdgcn_readfirstlane(nxt_item);
+        }
     }
 }
 

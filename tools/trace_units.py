@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Developer probe (GPU box): timeline of the search kernel's work units (IGT_DEV_FLAGS=256 + IGT_DEV_TRACE).
+Prints when the queues ran dry, how long the units took by class, and how many waves were busy over time."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'igt-mpc-int_amd'))
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+path = '/tmp/igt_trace.bin'
+os.environ['IGT_DEV_FLAGS'] = str(256 | int(os.environ.get('IGT_DEV_FLAGS', '0')))
+os.environ['IGT_DEV_TRACE'] = path
+import torch
+from igtmpc import BatchSolver
+from igtmpc.scenarios import make_batch
+b = make_batch(B, dtype=np.float32)
+args = [torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda() for a in (b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy'])]
+with BatchSolver(dtype='f32') as s:
+    for _ in range(3):
+        s.solve(*args)
+    torch.cuda.synchronize()
+tr = np.fromfile(path, dtype=np.uint64).reshape(-1, 4)
+tr = tr[tr[:, 1] > 0]
+t0 = tr[:, 0].astype(np.float64); t1 = tr[:, 1].astype(np.float64)
+base = t0.min(); t0 = (t0 - base) / 100.0; t1 = (t1 - base) / 100.0      # 100 MHz -> us
+p = (tr[:, 3] & 255).astype(int)
+dur = t1 - t0
+print(f'B={B}: {len(tr)} units on {len(np.unique(tr[:, 2]))} waves; kernel span {t1.max():.1f} us; last unit START at {t0.max():.1f} us')
+for pp in np.unique(p):
+    d = dur[p == pp]
+    print(f'  slice {pp}: n={len(d)} duration us: mean {d.mean():.1f} p50 {np.median(d):.1f} p90 {np.quantile(d, .9):.1f} p99 {np.quantile(d, .99):.1f} max {d.max():.1f}')
+grid = np.linspace(0, t1.max(), 21)
+busy = [(int(((t0 <= g) & (t1 > g)).sum())) for g in grid]
+print('  busy waves at 5% steps of the span:', busy)
+q = (tr[:, 2] % 8).astype(int)
+for qq in range(8):
+    m = q == qq
+    print(f'  queue {qq}: units {m.sum()}  first start {t0[m].min():.1f}  last start {t0[m].max():.1f}  last end {t1[m].max():.1f}  sum of durations {dur[m].sum()/1e3:.2f} ms  mean dur slice0 {dur[m & (p == 0)].mean():.1f} slice1 {dur[m & (p == 1)].mean():.1f}')
+late = np.argsort(-t1)[:8]
+print('  last finishers: ' + ', '.join(f'(start {t0[i]:.0f} dur {dur[i]:.0f} slice {p[i]})' for i in late))
