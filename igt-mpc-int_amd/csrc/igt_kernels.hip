@@ -345,44 +345,60 @@ __device__ __forceinline__ void search_unit(const KP& P, int W, int b, int p, co
 __device__ __forceinline__ int queue_scenario(int q, int j) { return 8 * j + ((q - j) & 7); }
 
 // Longest units first (small batches).  A unit's wall time is what the tail of the search kernel is made of, and units
-// differ 6x: the centre-steering slice runs the whole horizon while the others mostly leave through the early exit, and
-// a scenario that meets its arc within the horizon rolls the long sub-step variants.  One workgroup per queue sorts
-// its units into four classes -- (centre, arc) > (centre, straight) > (other, arc) > (other, straight) -- keeping the
-// scenario order inside a class (a stable counting sort, so the order is a function of the inputs alone).
+// differ 8x (16 .. 130 us at 2 waves per SIMD).  What the traces (tools/trace_units.py) and the oracle-side analysis
+// (tools/death_steps.py) show to matter:
+//   * the centre-steering slice runs (nearly) the whole horizon; the others leave through the early exit after a
+//     number of steps that falls with the speed (|e_y| grows with v: 18 steps at v0 < 1 m/s, 9 at v0 > 4);
+//   * a scenario that meets its arc within the horizon rolls the long sub-step variants (about 1.9x per step).
+// One workgroup per queue sorts its units into QC cost classes, most expensive first, keeping the scenario order
+// inside a class (a stable counting sort, so the order is a function of the inputs alone).
 // order[q][k] = (scenario ordinal in the queue) * 256 + slice.
+constexpr int QC = 8;
 __global__ __launch_bounds__(256) void build_queues_kernel(KP P, int B, int W, const float* __restrict__ x0,
                                                            const float* __restrict__ kparams,
                                                            unsigned* __restrict__ order, int stride) {
-    __shared__ int base[4];          // running offsets of the four classes
-    __shared__ int wave_cnt[4][4];   // [wave][class] counts of the current chunk
+    __shared__ int base[QC];         // running offsets of the classes
+    __shared__ int wave_cnt[4][QC];  // [wave][class] counts of the current chunk
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n_scen = (B + 7) / 8, n = n_scen * W;
     auto cls = [&](int i) {
         const int j = i / W, p = i - j * W, b = queue_scenario(q, j);
-        if (b >= B) return 3;                      // a hole of the last block of 8: sorts last, skipped by the search
+        if (b >= B) return QC - 1;                 // a hole of the last block of 8: sorts last, skipped by the search
         const float s0 = x0[(size_t)b * 7 + 2], v0 = x0[(size_t)b * 7 + 5];
         const float b0 = kparams[(size_t)b * 3 + 0], b1 = kparams[(size_t)b * 3 + 1], kv = kparams[(size_t)b * 3 + 2];
         const float reach = s0 + 1.5f * fmaxf(v0, 1.0f) * (float)(P.N * P.dt);
         const bool arc = kv != 0.0f && reach >= b0 && s0 <= b1;
-        return (p == 0 ? 0 : 2) + (arc ? 0 : 1);
+        const float frac = p == 0 ? 0.95f : fminf(fmaxf(1.05f - 0.15f * v0, 0.4f), 0.95f);   // share of the horizon rolled
+        const float cost = frac * (arc ? 1.9f : 1.0f);                                        // 0.4 .. 1.8
+        const int c = (int)((1.85f - cost) * ((float)QC / 1.5f));
+        return c < 0 ? 0 : (c > QC - 1 ? QC - 1 : c);
     };
     // pass 1: class totals -> class bases
-    int cnt[4] = {0, 0, 0, 0};
-    for (int i = tid; i < n; i += 256) cnt[cls(i)]++;
-    if (tid < 4) base[tid] = 0;
+    int cnt[QC];
+#pragma unroll
+    for (int c = 0; c < QC; ++c) cnt[c] = 0;
+    for (int i = tid; i < n; i += 256) {
+        const int ci = cls(i);
+#pragma unroll
+        for (int c = 0; c < QC; ++c) cnt[c] += ci == c;
+    }
+    if (tid < QC) base[tid] = 0;
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < QC; ++c) {
         int v = cnt[c];
         for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0) atomicAdd(&base[c], v);      // integer sums: order of the adds does not matter
+        if (lane == 0) atomicAdd(&base[c], v);      // integer sums: the order of the adds does not matter
     }
     __syncthreads();
-    int tot[4];
+    int tot[QC];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) tot[c] = base[c];
+    for (int c = 0; c < QC; ++c) tot[c] = base[c];
     __syncthreads();
-    if (tid == 0) { base[0] = 0; base[1] = tot[0]; base[2] = tot[0] + tot[1]; base[3] = tot[0] + tot[1] + tot[2]; }
+    if (tid == 0) {
+        int run = 0;
+        for (int c = 0; c < QC; ++c) { base[c] = run; run += tot[c]; }
+    }
     __syncthreads();
     // pass 2: stable scatter, 256 items per trip in index order
     for (int i0 = 0; i0 < n; i0 += 256) {
@@ -390,7 +406,7 @@ __global__ __launch_bounds__(256) void build_queues_kernel(KP P, int B, int W, c
         const int c = i < n ? cls(i) : -1;
         int rank = 0;
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
+        for (int cc = 0; cc < QC; ++cc) {
             const unsigned long long m = __ballot(c == cc);
             if (lane == 0) wave_cnt[wv][cc] = __popcll(m);
             if (c == cc) rank = __popcll(m & ((1ull << lane) - 1ull));
@@ -403,7 +419,7 @@ __global__ __launch_bounds__(256) void build_queues_kernel(KP P, int B, int W, c
             order[(size_t)q * stride + off] = (unsigned)j * 256u + (unsigned)p;
         }
         __syncthreads();
-        if (tid < 4) base[tid] += wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid];
+        if (tid < QC) base[tid] += wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid];
         __syncthreads();
     }
 }
@@ -775,8 +791,9 @@ template <int CAND, bool HI, bool VALUE>
 static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>& A, hipStream_t st) {
     const int W = (P.C + 127) / 128;
     const size_t total = (size_t)B * W;
-    // persistent waves on per-XCD queues; 3 per SIMD once there are >= 10 units per wave slot, else 2 per SIMD
-    const bool big = total >= (size_t)A.n_cu * 12 * 10;
+    // persistent waves on per-XCD queues; 3 per SIMD once there are >= 16 units per wave slot (B >= 24 576 at C = 256,
+    // measured crossover), else 2 per SIMD
+    const bool big = total >= (size_t)A.n_cu * 12 * 16;
     const bool o3 = (P.dev & 8) ? false : (P.dev & 32) ? true : big;
     const size_t slots = (size_t)A.n_cu * 4 * (o3 ? 3 : 2);
     const size_t grid = total < slots ? total : slots;
