@@ -145,6 +145,10 @@ struct Arena {   // carves 256-byte aligned pieces out of the staging buffer
     }
 };
 
+// the queue builder of small float batches zeroes the search kernel's unit counters itself
+inline bool counters_by_builder(const igt::KP& kp, int B, const igt::SolveArgs<float>& A) { return igt::search_builds_queues(kp, B, A); }
+inline bool counters_by_builder(const igt::KP&, int, const igt::SolveArgs<double>&) { return false; }
+
 template <typename T>
 int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* kparams, const uint32_t* flags,
                const T* obs_xy, const T* tv_sv, const T* enc, T* x_out, T* u_out, T* cost_out, int32_t* argmin_out,
@@ -241,7 +245,7 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
         A.cpar = it == 0 ? nullptr : d_cpar;
         if (value) {
             if (compact) {
-                HIPCHK(hipMemsetAsync(A.work_counter, 0, 8 * 256, st));
+                if (!counters_by_builder(kp, B, A)) HIPCHK(hipMemsetAsync(A.work_counter, 0, 8 * 256, st));
                 HIPCHK(hipMemsetAsync(A.rec_count, 0, 256, st));
                 HIPCHK(hipMemsetAsync(A.best_key, 0xff, (size_t)B * 8, st));
             }
@@ -249,7 +253,7 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
             HIPCHK(igt::launch_value<T>(kp, B, net_of<T>(h), A, nullptr, nullptr, st));
             if (sizeof(T) == 8) HIPCHK(igt::launch_reduce<T>(B, (int)W, A, st));
         } else {
-            if (sizeof(T) == 4) HIPCHK(hipMemsetAsync(A.work_counter, 0, 8 * 256, st));
+            if (sizeof(T) == 4 && !counters_by_builder(kp, B, A)) HIPCHK(hipMemsetAsync(A.work_counter, 0, 8 * 256, st));
             HIPCHK(igt::launch_search<T>(kp, B, A, h->nc, st));
         }
         if (it < p.refine_iters) {   // winner of this pass -> centre / span of the next one

@@ -353,74 +353,58 @@ __device__ __forceinline__ int queue_scenario(int q, int j) { return 8 * j + ((q
 // One workgroup per queue sorts its units into QC cost classes, most expensive first, keeping the scenario order
 // inside a class (a stable counting sort, so the order is a function of the inputs alone).
 // order[q][k] = (scenario ordinal in the queue) * 256 + slice.
-constexpr int QC = 8;
-__global__ __launch_bounds__(256) void build_queues_kernel(KP P, int B, int W, const float* __restrict__ x0,
-                                                           const float* __restrict__ kparams,
-                                                           unsigned* __restrict__ order, int stride) {
-    __shared__ int base[QC];         // running offsets of the classes
-    __shared__ int wave_cnt[4][QC];  // [wave][class] counts of the current chunk
+constexpr int QC = 8, QB_THREADS = 1024, QB_TRIPS = 2;     // up to 2048 units per queue (B <= 8192 at W = 2)
+__global__ __launch_bounds__(QB_THREADS) void build_queues_kernel(KP P, int B, int W, const float* __restrict__ x0,
+                                                                  const float* __restrict__ kparams,
+                                                                  unsigned* __restrict__ order, int stride,
+                                                                  unsigned* __restrict__ work_counter) {
+    __shared__ int cnt[QB_TRIPS][QB_THREADS / 64][QC];   // [trip][wave][class] counts, then exclusive offsets
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) work_counter[q * 64] = 0u;             // this queue's unit counter (saves the memset node)
     const int n_scen = (B + 7) / 8, n = n_scen * W;
-    auto cls = [&](int i) {
-        const int j = i / W, p = i - j * W, b = queue_scenario(q, j);
-        if (b >= B) return QC - 1;                 // a hole of the last block of 8: sorts last, skipped by the search
-        const float s0 = x0[(size_t)b * 7 + 2], v0 = x0[(size_t)b * 7 + 5];
-        const float b0 = kparams[(size_t)b * 3 + 0], b1 = kparams[(size_t)b * 3 + 1], kv = kparams[(size_t)b * 3 + 2];
-        const float reach = s0 + 1.5f * fmaxf(v0, 1.0f) * (float)(P.N * P.dt);
-        const bool arc = kv != 0.0f && reach >= b0 && s0 <= b1;
-        const float frac = p == 0 ? 0.95f : fminf(fmaxf(1.05f - 0.15f * v0, 0.4f), 0.95f);   // share of the horizon rolled
-        const float cost = frac * (arc ? 1.9f : 1.0f);                                        // 0.4 .. 1.8
-        const int c = (int)((1.85f - cost) * ((float)QC / 1.5f));
-        return c < 0 ? 0 : (c > QC - 1 ? QC - 1 : c);
-    };
-    // pass 1: class totals -> class bases
-    int cnt[QC];
+    int cls[QB_TRIPS], rank[QB_TRIPS];
 #pragma unroll
-    for (int c = 0; c < QC; ++c) cnt[c] = 0;
-    for (int i = tid; i < n; i += 256) {
-        const int ci = cls(i);
-#pragma unroll
-        for (int c = 0; c < QC; ++c) cnt[c] += ci == c;
-    }
-    if (tid < QC) base[tid] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < QC; ++c) {
-        int v = cnt[c];
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0) atomicAdd(&base[c], v);      // integer sums: the order of the adds does not matter
-    }
-    __syncthreads();
-    int tot[QC];
-#pragma unroll
-    for (int c = 0; c < QC; ++c) tot[c] = base[c];
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int c = 0; c < QC; ++c) { base[c] = run; run += tot[c]; }
-    }
-    __syncthreads();
-    // pass 2: stable scatter, 256 items per trip in index order
-    for (int i0 = 0; i0 < n; i0 += 256) {
-        const int i = i0 + tid;
-        const int c = i < n ? cls(i) : -1;
-        int rank = 0;
+    for (int t = 0; t < QB_TRIPS; ++t) {
+        const int i = t * QB_THREADS + tid;
+        int c = -1;
+        if (i < n) {
+            const int j = i / W, p = i - j * W, b = queue_scenario(q, j);
+            c = QC - 1;                                  // a hole of the last block of 8: sorts last, skipped by the search
+            if (b < B) {
+                const float s0 = x0[(size_t)b * 7 + 2], v0 = x0[(size_t)b * 7 + 5];
+                const float b0 = kparams[(size_t)b * 3 + 0], b1 = kparams[(size_t)b * 3 + 1], kv = kparams[(size_t)b * 3 + 2];
+                const float reach = s0 + 1.5f * fmaxf(v0, 1.0f) * (float)(P.N * P.dt);
+                const bool arc = kv != 0.0f && reach >= b0 && s0 <= b1;
+                const float frac = p == 0 ? 0.95f : fminf(fmaxf(1.05f - 0.15f * v0, 0.4f), 0.95f);   // share of the horizon rolled
+                const float cost = frac * (arc ? 1.9f : 1.0f);                                        // 0.4 .. 1.8
+                c = (int)((1.85f - cost) * ((float)QC / 1.5f));
+                c = c < 0 ? 0 : (c > QC - 1 ? QC - 1 : c);
+            }
+        }
+        cls[t] = c; rank[t] = 0;
 #pragma unroll
         for (int cc = 0; cc < QC; ++cc) {
             const unsigned long long m = __ballot(c == cc);
-            if (lane == 0) wave_cnt[wv][cc] = __popcll(m);
-            if (c == cc) rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) cnt[t][wv][cc] = __popcll(m);
+            if (c == cc) rank[t] = __popcll(m & ((1ull << lane) - 1ull));
         }
-        __syncthreads();
-        if (c >= 0) {
-            int off = base[c] + rank;
-            for (int w2 = 0; w2 < wv; ++w2) off += wave_cnt[w2][c];
-            const int j = i / W, p = i - j * W;
-            order[(size_t)q * stride + off] = (unsigned)j * 256u + (unsigned)p;
-        }
-        __syncthreads();
-        if (tid < QC) base[tid] += wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid];
-        __syncthreads();
+    }
+    __syncthreads();
+    __shared__ int total[QC];
+    if (tid < QC) {          // per class: exclusive offsets in index order (trip, wave), and the class total
+        int run = 0;
+        for (int t = 0; t < QB_TRIPS; ++t)
+            for (int w2 = 0; w2 < QB_THREADS / 64; ++w2) { const int v = cnt[t][w2][tid]; cnt[t][w2][tid] = run; run += v; }
+        total[tid] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < QB_TRIPS; ++t) {
+        if (cls[t] < 0) continue;
+        int off = cnt[t][wv][cls[t]] + rank[t];
+        for (int cc = 0; cc < cls[t]; ++cc) off += total[cc];      // the more expensive classes come first
+        const int i = t * QB_THREADS + tid, j = i / W, p = i - j * W;
+        order[(size_t)q * stride + off] = (unsigned)j * 256u + (unsigned)p;
     }
 }
 
@@ -787,6 +771,12 @@ static hipError_t launch_search_exact(const KP& P, int B, const SolveArgs<double
     return hipGetLastError();
 }
 
+// whether launch_search_fast will run build_queues_kernel (which also zeroes the unit counters)
+bool search_builds_queues(const KP& P, int B, const SolveArgs<float>& A) {
+    const int W = (P.C + 127) / 128;
+    return A.queue_order && W <= 256 && ((B + 7) / 8) * W <= QB_THREADS * QB_TRIPS && !(P.dev & 16);
+}
+
 template <int CAND, bool HI, bool VALUE>
 static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>& A, hipStream_t st) {
     const int W = (P.C + 127) / 128;
@@ -799,8 +789,9 @@ static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>&
     const size_t grid = total < slots ? total : slots;
     const unsigned* order = nullptr;
     const int order_stride = ((B + 7) / 8) * W;
-    if (A.queue_order && W <= 256 && !(P.dev & 16)) {        // small batches: longest units first
-        hipLaunchKernelGGL(build_queues_kernel, dim3(8), dim3(256), 0, st, P, B, W, A.x0, A.kparams, A.queue_order, order_stride);
+    if (search_builds_queues(P, B, A)) {                     // small batches: longest units first
+        hipLaunchKernelGGL(build_queues_kernel, dim3(8), dim3(QB_THREADS), 0, st, P, B, W, A.x0, A.kparams, A.queue_order,
+                           order_stride, A.work_counter);
         order = A.queue_order;
     }
     if (o3)
