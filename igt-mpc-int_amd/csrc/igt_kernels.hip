@@ -265,11 +265,50 @@ struct PairSink {
     }
 };
 
+// Which candidates a unit (slice p of W) rolls on which lane, and the inverse.  Generated G x G families with
+// W * 128 == C and W | G: a slice takes G/W STEERING values (all G accelerations), the values handed out from the centre
+// of the range outwards.  The |e_y| verdict (87 % of all failures) depends mostly on the steering sequence, so the
+// slices holding the extreme steering values fail as a whole within a few steps and leave through the early exit
+// (tools/death_steps.py: 23 % fewer wave-steps than slices cut along the acceleration axis).  Pairs still share their
+// steering column: (i, j) and (i + G/2, j).  Otherwise: chunks of 64 in index order, two per slice.
+template <int CAND>
+__device__ __forceinline__ bool steering_slices(const KP& P, int W) {
+    return CAND != CAND_TABLE && P.G * P.G == P.C && W * 128 == P.C && P.G % W == 0 && !(P.dev & 1);
+}
+template <int CAND>
+__device__ __forceinline__ void slice_candidates(const KP& P, int W, int p, int lane, int (&cidx)[2]) {
+    const int chunks = P.C / 64;
+    // an odd number of 64-candidate chunks: the last slice rolls its chunk twice (harmless duplicate)
+    cidx[0] = (2 * p) * 64 + lane;
+    cidx[1] = (2 * p + 1 < chunks ? 2 * p + 1 : 2 * p) * 64 + lane;
+    if (steering_slices<CAND>(P, W)) {
+        const int nj = P.G / W, jl = lane % nj, il = lane / nj, r = p * nj + jl;
+        const int j = (r & 1) ? P.G / 2 - 1 - (r >> 1) : P.G / 2 + (r >> 1);
+        cidx[0] = il * P.G + j;
+        cidx[1] = (il + P.G / 2) * P.G + j;
+    }
+}
+template <int CAND>
+__device__ __forceinline__ void candidate_slot(const KP& P, int W, int c, int& p, int& slot) {   // slot = 64 q + lane
+    if (steering_slices<CAND>(P, W)) {
+        const int i = c / P.G, j = c - i * P.G, nj = P.G / W;
+        const int r = j >= P.G / 2 ? 2 * (j - P.G / 2) : 2 * (P.G / 2 - 1 - j) + 1;
+        const int q = i >= P.G / 2 ? 1 : 0, il = i - q * (P.G / 2);
+        p = r / nj;
+        slot = 64 * q + il * nj + (r - p * nj);
+    } else {
+        const int chunk = c / 64;
+        p = chunk / 2;
+        slot = 64 * (chunk & 1) + (c & 63);
+    }
+}
+
 // One work unit = one (scenario, 128-candidate slice): W = ceil(C/128) units per scenario.  A unit is rolled by
 // one 64-lane wave and leaves its slice's best (J, c); emit_fast_kernel reduces the W partials (ties -> lowest
 // candidate index).
-template <int CAND, bool HI, bool VALUE>
-__device__ __forceinline__ void search_unit(const KP& P, int W, int b, int p, const float* __restrict__ x0,
+template <int CAND, bool HI, bool VALUE, bool CKPT>
+__device__ __forceinline__ void search_unit(const KP& P, int W, int b, int p, double* __restrict__ ckpt, int n_units,
+                                            const float* __restrict__ x0,
                                             const float* __restrict__ u_prev, const float* __restrict__ kparams,
                                             const uint32_t* __restrict__ flags, const float* __restrict__ obs,
                                             const double* __restrict__ table, const double* __restrict__ cinf,
@@ -283,23 +322,12 @@ __device__ __forceinline__ void search_unit(const KP& P, int W, int b, int p, co
     Scenario<float> S;
     load_scenario<float>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
     NullSink sink;
-    const int chunks = P.C / 64;
-    // an odd number of 64-candidate chunks: the last slice rolls its chunk twice (harmless duplicate)
-    int cidx[2] = {(2 * p) * 64 + lane, (2 * p + 1 < chunks ? 2 * p + 1 : 2 * p) * 64 + lane};
-    if (CAND != CAND_TABLE && P.G * P.G == P.C && W * 128 == P.C && P.G % W == 0 && !(P.dev & 1)) {
-        // Generated G x G families: a slice takes G/W STEERING values (all G accelerations), the values handed
-        // out from the centre of the range outwards.  The |e_y| verdict (87 % of all failures) depends mostly
-        // on the steering sequence, so the slices holding the extreme steering values fail as a whole within a
-        // few steps and leave through the early exit (tools/death_steps.py: 23 % fewer wave-steps than slices
-        // cut along the acceleration axis).  Pairs still share their steering column: (i, j) and (i + G/2, j).
-        const int nj = P.G / W, jl = lane % nj, il = lane / nj, r = p * nj + jl;
-        const int j = (r & 1) ? P.G / 2 - 1 - (r >> 1) : P.G / 2 + (r >> 1);
-        cidx[0] = il * P.G + j;
-        cidx[1] = (il + P.G / 2) * P.G + j;
-    }
+    int cidx[2];
+    slice_candidates<CAND>(P, W, p, lane, cidx);
     double J[2], sN[2], vN[2];
     unsigned viol[2];
-    rollout_pair<CAND, HI, true, true, float, NullSink, true>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
+    const Ckpt ck{CKPT ? ckpt : nullptr, (size_t)n_units, gw, lane};
+    rollout_pair<CAND, HI, true, true, float, NullSink, true, CKPT>(P, S, cidx, table, cinf, sink, J, viol, sN, vN, ck);
     if (VALUE) {   // terminal value network (mpc.py:369): append the feasible candidates for the value kernels
         const bool dup = cidx[1] == cidx[0];                       // odd chunk count: second half is a duplicate
         const bool ok0 = viol[0] == 0 && finite_d(J[0]), ok1 = viol[1] == 0 && finite_d(J[1]) && !dup;
@@ -416,10 +444,10 @@ __global__ __launch_bounds__(QB_THREADS) void build_queues_kernel(KP P, int B, i
 // small batch behind each other.  Hence one counter per XCD (workgroup n runs on XCD n mod 8), 256 B apart; queue q
 // owns one scenario of every block of 8 (queue_scenario) and deals them out scenario-major, or longest first when
 // the batch is small (build_queues_kernel); a wave whose queue is dry takes from the other queues in turn.
-template <int CAND, bool HI, bool VALUE>
+template <int CAND, bool HI, bool VALUE, bool CKPT>
 __device__ __forceinline__ void search_waves(
     const KP& P, int B, int W, int queues, unsigned* __restrict__ work_counter, const unsigned* __restrict__ order,
-    int order_stride, const float* __restrict__ x0, const float* __restrict__ u_prev, const float* __restrict__ kparams, const uint32_t* __restrict__ flags,
+    int order_stride, double* __restrict__ ckpt, const float* __restrict__ x0, const float* __restrict__ u_prev, const float* __restrict__ kparams, const uint32_t* __restrict__ flags,
     const float* __restrict__ obs, const double* __restrict__ table, const double* __restrict__ cinf,
     const double* __restrict__ cpar, double* __restrict__ part_J, int32_t* __restrict__ part_c,
     float* __restrict__ rec_sN, float* __restrict__ rec_vN, double* __restrict__ rec_J,
@@ -460,7 +488,7 @@ __device__ __forceinline__ void search_waves(
             const unsigned long long t0 = (P.dev & 256) ? wall_clock64() : 0ull;
             const int b = queue_scenario((int)qq, (int)j);
             if (b < B)
-                search_unit<CAND, HI, VALUE>(P, W, b, (int)p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J,
+                search_unit<CAND, HI, VALUE, CKPT>(P, W, b, (int)p, ckpt, B * W, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J,
                                              part_c, rec_sN, rec_vN, rec_J, rec_viol, rec_count, rec_b);
             if ((P.dev & 256) && lane0) {      // developer trace (IGT_DEV_TRACE): when each unit ran, and where
                 unsigned long long* tr =
@@ -481,22 +509,22 @@ __device__ __forceinline__ void search_waves(
 // busy on big batches; 2 per SIMD (no spill) rolls a unit in less wall time, which is what bounds a small batch.
 #define IGT_SEARCH_ARGS                                                                                              \
     KP P, int B, int W, int queues, unsigned* __restrict__ work_counter, const unsigned* __restrict__ order,          \
-        int order_stride, const float* __restrict__ x0,                                                                 \
+        int order_stride, double* __restrict__ ckpt, const float* __restrict__ x0,                                      \
         const float* __restrict__ u_prev, const float* __restrict__ kparams, const uint32_t* __restrict__ flags,     \
         const float* __restrict__ obs, const double* __restrict__ table, const double* __restrict__ cinf,            \
         const double* __restrict__ cpar, double* __restrict__ part_J, int32_t* __restrict__ part_c,                  \
         float* __restrict__ rec_sN, float* __restrict__ rec_vN, double* __restrict__ rec_J,                          \
         uint32_t* __restrict__ rec_viol, unsigned* __restrict__ rec_count, int32_t* __restrict__ rec_b
 #define IGT_SEARCH_PASS                                                                                              \
-    P, B, W, queues, work_counter, order, order_stride, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J,    \
+    P, B, W, queues, work_counter, order, order_stride, ckpt, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J,    \
         part_c, rec_sN, rec_vN, rec_J, rec_viol, rec_count, rec_b
 template <int CAND, bool HI, bool VALUE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void search_fast_kernel_o3(IGT_SEARCH_ARGS) {
-    search_waves<CAND, HI, VALUE>(IGT_SEARCH_PASS);
+    search_waves<CAND, HI, VALUE, false>(IGT_SEARCH_PASS);
 }
 template <int CAND, bool HI, bool VALUE>
-__global__ __launch_bounds__(64) void search_fast_kernel_o2(IGT_SEARCH_ARGS) {
-    search_waves<CAND, HI, VALUE>(IGT_SEARCH_PASS);
+__global__ __launch_bounds__(64) void search_fast_kernel_o2(IGT_SEARCH_ARGS) {    // the build that can leave checkpoints
+    search_waves<CAND, HI, VALUE, true>(IGT_SEARCH_PASS);
 }
 
 template <int CAND, bool HI>
@@ -541,6 +569,59 @@ __global__ __launch_bounds__(64) void emit_fast_kernel(KP P, int B, int W, const
     double J[1], sN[1], vN[1];
     unsigned viol[1];
     single::rollout_pair<CAND, HI, false, false, float>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
+}
+
+// The same, from the search pass's checkpoints (small batches): four lanes per scenario roll the four quarters of the
+// winner's horizon at once -- a lone roll-out is latency, and this is a quarter of it.
+template <int CAND, bool HI>
+__global__ __launch_bounds__(64) void emit_seg_kernel(KP P, int B, int W, int Wk, const float* __restrict__ x0,
+                                                      const float* __restrict__ u_prev,
+                                                      const float* __restrict__ kparams,
+                                                      const uint32_t* __restrict__ flags,
+                                                      const float* __restrict__ obs,
+                                                      const double* __restrict__ table,
+                                                      const double* __restrict__ cinf, const double* __restrict__ cpar,
+                                                      const double* __restrict__ part_J,
+                                                      const int32_t* __restrict__ part_c,
+                                                      const double* __restrict__ ckpt,
+                                                      float* __restrict__ cost_out, int32_t* __restrict__ argmin_out,
+                                                      int32_t* __restrict__ status_out, float* __restrict__ x_out,
+                                                      float* __restrict__ u_out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = t / SEG_PARTS, g = t - b * SEG_PARTS;
+    if (b >= B) return;
+    double bestJ = 0.0;
+    int c = -1;
+    for (int w = 0; w < W; ++w) {
+        const int cw = part_c[(size_t)b * W + w];
+        const double Jw = part_J[(size_t)b * W + w];
+        if (cw >= 0 && (c < 0 || Jw < bestJ)) { bestJ = Jw; c = cw; }
+    }
+    float* xo = x_out + (size_t)b * 7 * (P.N + 1);
+    float* uo = u_out + (size_t)b * 2 * P.N;
+    if (g == 0) {
+        cost_out[b] = c >= 0 ? (float)bestJ : INFINITY;
+        argmin_out[b] = c;
+        status_out[b] = c >= 0 ? 0 : 1;
+        if (c < 0) {  // is_opt False (mpc.py:402-406): no trajectory
+            for (int i = 0; i < 7 * (P.N + 1); ++i) xo[i] = NAN;
+            for (int i = 0; i < 2 * P.N; ++i) uo[i] = NAN;
+        }
+    }
+    if (c < 0) return;
+    Scenario<float> S;
+    load_scenario<float>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
+    int p, slot;
+    candidate_slot<CAND>(P, Wk, c, p, slot);
+    const int ns = P.N / SEG_PARTS;
+    const size_t n_units = (size_t)B * Wk, unit = (size_t)b * Wk + p;
+    const Seg seg{g * ns, (g + 1) * ns, g > 0 ? ckpt + ((size_t)(g - 1) * n_units + unit) * SEG_UNIT_DOUBLES : nullptr, slot};
+    PairSink<float> sink{{xo, nullptr}, {uo, nullptr}, P.N};
+    const int cidx[1] = {c};
+    double J[1], sN[1], vN[1];
+    unsigned viol[1];
+    single::rollout_pair<CAND, HI, false, false, float, PairSink<float>, false, false, true>(
+        P, S, cidx, table, cinf, sink, J, viol, sN, vN, Ckpt{nullptr, 0, 0, 0}, seg);
 }
 
 template <int CAND, bool HI>
@@ -796,11 +877,11 @@ static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>&
     }
     if (o3)
         hipLaunchKernelGGL((search_fast_kernel_o3<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
-                           order, order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN,
+                           order, order_stride, A.ckpt, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN,
                            A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
     else
         hipLaunchKernelGGL((search_fast_kernel_o2<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
-                           order, order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN,
+                           order, order_stride, A.ckpt, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN,
                            A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
     return hipGetLastError();
 }
@@ -916,6 +997,13 @@ template hipError_t launch_reduce<double>(int, int, const SolveArgs<double>&, hi
 
 template <int CAND, bool HI>
 static hipError_t launch_emit_fast(const KP& P, int B, int W, const SolveArgs<float>& A, hipStream_t st) {
+    if (A.ckpt) {
+        const int Wk = (P.C + 127) / 128;
+        hipLaunchKernelGGL((emit_seg_kernel<CAND, HI>), dim3(((size_t)B * SEG_PARTS + 63) / 64), dim3(64), 0, st, P, B, W, Wk,
+                           A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.ckpt,
+                           A.cost_out, A.argmin_out, A.status_out, A.x_out, A.u_out);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((emit_fast_kernel<CAND, HI>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, W, A.x0, A.u_prev,
                        A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.cost_out, A.argmin_out,
                        A.status_out, A.x_out, A.u_out);
