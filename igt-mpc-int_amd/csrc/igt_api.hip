@@ -210,9 +210,19 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     const bool compact = value && sizeof(T) == 4;
     const size_t W = compact ? 1 : (value ? (size_t)p.C / 64 : ((size_t)p.C + 127) / 128);
     const size_t Wk = ((size_t)p.C + 127) / 128;          // units per scenario of the float search kernel
-    bool use_ckpt = sizeof(T) == 4 && p.N % igt::SEG_PARTS == 0 && p.N >= 2 * igt::SEG_PARTS && B <= 6144;   // +15 % at B = 1024, +3 % at 4096, nothing from 8192 on
-    if (const char* e = std::getenv("IGT_DEV_CKPT")) use_ckpt = use_ckpt && std::atoi(e) != 0;
-    const size_t ckpt_bytes = use_ckpt ? (size_t)(igt::SEG_PARTS - 1) * B * Wk * igt::SEG_UNIT_DOUBLES * 8 + 256 : 0;
+    // small float batches: emit in pieces from checkpoints of the search pass (4 pieces up to B = 4096, 2 up to 6144,
+    // measured: the records cost the search pass bandwidth, the pieces save emit latency)
+    int ck_parts = 1;
+    if (sizeof(T) == 4 && B <= 6144) {
+        if (B <= 4096 && p.N % 4 == 0 && p.N >= 8) ck_parts = 4;
+        else if (p.N % 2 == 0 && p.N >= 4) ck_parts = 2;
+    }
+    if (const char* e = std::getenv("IGT_DEV_CKPT")) {
+        const int v = std::atoi(e);
+        if (sizeof(T) == 4 && v >= 1 && v <= igt::SEG_MAX_PARTS && p.N % v == 0 && p.N >= 2 * v) ck_parts = v;
+    }
+    const bool use_ckpt = ck_parts > 1;
+    const size_t ckpt_bytes = use_ckpt ? (size_t)(ck_parts - 1) * B * Wk * igt::SEG_UNIT_DOUBLES * 8 + 256 : 0;
     double *d_cpar = nullptr, *d_uprev = nullptr;
     {
         const size_t n_rec = value ? (size_t)B * p.C : 0;
@@ -228,7 +238,8 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
         A.work_counter = wa.take<unsigned>(1024 + (trace ? (size_t)((B + 7) / 8) * 8 * Wk * 8 : 0));
         A.n_cu = h->n_cu;
         // small batches: the search pass leaves horizon checkpoints, emit rolls the winner's four quarters at once
-        A.ckpt = use_ckpt ? wa.take<double>((size_t)(igt::SEG_PARTS - 1) * B * Wk * igt::SEG_UNIT_DOUBLES) : nullptr;
+        A.ckpt = use_ckpt ? wa.take<double>((size_t)(ck_parts - 1) * B * Wk * igt::SEG_UNIT_DOUBLES) : nullptr;
+        A.ck_parts = ck_parts;
         // small batches: the search queues are sorted longest unit first (build_queues_kernel; 3-5 % up to B = 4096,
         // nothing from 8192 on)
         A.queue_order = (sizeof(T) == 4 && B <= 6144) ? wa.take<unsigned>((size_t)((B + 7) / 8) * 8 * Wk) : nullptr;

@@ -259,12 +259,13 @@ struct Scenario {           // wave-uniform inputs of one scenario
     const T* obs;           // [n_obs, 2, N+1]
 };
 
-// Horizon checkpoints (small batches).  The search pass leaves every still-feasible candidate's state at the control
-// steps N/4, N/2, 3N/4 in HBM, exactly (doubles and floats as they are); emit then rolls the winner's four quarters of
-// the horizon on four lanes at once, each resuming from a checkpoint -- bit for bit the unsegmented roll-out.
+// Horizon checkpoints (small batches).  The search pass leaves every still-feasible candidate's state at `parts - 1`
+// evenly spaced control steps in HBM, exactly (doubles and floats as they are); emit then rolls the winner's `parts`
+// pieces of the horizon on as many lanes at once, each resuming from a checkpoint -- bit for bit the unsegmented
+// roll-out.  parts = 4 up to B = 4096, 2 up to 6144 (the records cost the search pass bandwidth), none above.
 // One unit's record: SEG_FIELDS x 128 slots x 8 B, slot = 64 q + lane of the search wave.
 //   fields 0..9: x y s ey epsi v psi J a df (double); 10: (sin,cos)(psi+beta) floats; 11: (cos,sin)(beta_{k-1}) floats
-constexpr int SEG_FIELDS = 12, SEG_SLOTS = 128, SEG_PARTS = 4;
+constexpr int SEG_FIELDS = 12, SEG_SLOTS = 128, SEG_MAX_PARTS = 4;
 constexpr size_t SEG_UNIT_DOUBLES = (size_t)SEG_FIELDS * SEG_SLOTS;
 struct Seg {
     int k0, k1;              // this call rolls control steps [k0, k1)
@@ -272,9 +273,10 @@ struct Seg {
     int slot0;               // slot of candidate q of this lane = slot0 + 64 q
 };
 struct Ckpt {
-    double* base;            // [SEG_PARTS-1][n_units] records (null: no checkpoints)
+    double* base;            // [parts-1][n_units] records (null: no checkpoints)
     size_t n_units;
     int unit, slot0;
+    int every;               // control steps between checkpoints = N / parts
 };
 
 struct NullSink {

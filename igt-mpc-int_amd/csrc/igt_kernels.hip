@@ -307,7 +307,8 @@ __device__ __forceinline__ void candidate_slot(const KP& P, int W, int c, int& p
 // one 64-lane wave and leaves its slice's best (J, c); emit_fast_kernel reduces the W partials (ties -> lowest
 // candidate index).
 template <int CAND, bool HI, bool VALUE, bool CKPT>
-__device__ __forceinline__ void search_unit(const KP& P, int W, int b, int p, double* __restrict__ ckpt, int n_units,
+__device__ __forceinline__ void search_unit(const KP& P, int W, int b, int p, double* __restrict__ ckpt, int ck_parts,
+                                            int n_units,
                                             const float* __restrict__ x0,
                                             const float* __restrict__ u_prev, const float* __restrict__ kparams,
                                             const uint32_t* __restrict__ flags, const float* __restrict__ obs,
@@ -326,7 +327,7 @@ __device__ __forceinline__ void search_unit(const KP& P, int W, int b, int p, do
     slice_candidates<CAND>(P, W, p, lane, cidx);
     double J[2], sN[2], vN[2];
     unsigned viol[2];
-    const Ckpt ck{CKPT ? ckpt : nullptr, (size_t)n_units, gw, lane};
+    const Ckpt ck{CKPT && ck_parts > 1 ? ckpt : nullptr, (size_t)n_units, gw, lane, ck_parts > 1 ? P.N / ck_parts : 0};
     rollout_pair<CAND, HI, true, true, float, NullSink, true, CKPT>(P, S, cidx, table, cinf, sink, J, viol, sN, vN, ck);
     if (VALUE) {   // terminal value network (mpc.py:369): append the feasible candidates for the value kernels
         const bool dup = cidx[1] == cidx[0];                       // odd chunk count: second half is a duplicate
@@ -447,7 +448,8 @@ __global__ __launch_bounds__(QB_THREADS) void build_queues_kernel(KP P, int B, i
 template <int CAND, bool HI, bool VALUE, bool CKPT>
 __device__ __forceinline__ void search_waves(
     const KP& P, int B, int W, int queues, unsigned* __restrict__ work_counter, const unsigned* __restrict__ order,
-    int order_stride, double* __restrict__ ckpt, const float* __restrict__ x0, const float* __restrict__ u_prev, const float* __restrict__ kparams, const uint32_t* __restrict__ flags,
+    int order_stride, double* __restrict__ ckpt, int ck_parts, const float* __restrict__ x0,
+    const float* __restrict__ u_prev, const float* __restrict__ kparams, const uint32_t* __restrict__ flags,
     const float* __restrict__ obs, const double* __restrict__ table, const double* __restrict__ cinf,
     const double* __restrict__ cpar, double* __restrict__ part_J, int32_t* __restrict__ part_c,
     float* __restrict__ rec_sN, float* __restrict__ rec_vN, double* __restrict__ rec_J,
@@ -488,7 +490,7 @@ __device__ __forceinline__ void search_waves(
             const unsigned long long t0 = (P.dev & 256) ? wall_clock64() : 0ull;
             const int b = queue_scenario((int)qq, (int)j);
             if (b < B)
-                search_unit<CAND, HI, VALUE, CKPT>(P, W, b, (int)p, ckpt, B * W, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J,
+                search_unit<CAND, HI, VALUE, CKPT>(P, W, b, (int)p, ckpt, ck_parts, B * W, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J,
                                              part_c, rec_sN, rec_vN, rec_J, rec_viol, rec_count, rec_b);
             if ((P.dev & 256) && lane0) {      // developer trace (IGT_DEV_TRACE): when each unit ran, and where
                 unsigned long long* tr =
@@ -509,14 +511,14 @@ __device__ __forceinline__ void search_waves(
 // busy on big batches; 2 per SIMD (no spill) rolls a unit in less wall time, which is what bounds a small batch.
 #define IGT_SEARCH_ARGS                                                                                              \
     KP P, int B, int W, int queues, unsigned* __restrict__ work_counter, const unsigned* __restrict__ order,          \
-        int order_stride, double* __restrict__ ckpt, const float* __restrict__ x0,                                      \
+        int order_stride, double* __restrict__ ckpt, int ck_parts, const float* __restrict__ x0,                        \
         const float* __restrict__ u_prev, const float* __restrict__ kparams, const uint32_t* __restrict__ flags,     \
         const float* __restrict__ obs, const double* __restrict__ table, const double* __restrict__ cinf,            \
         const double* __restrict__ cpar, double* __restrict__ part_J, int32_t* __restrict__ part_c,                  \
         float* __restrict__ rec_sN, float* __restrict__ rec_vN, double* __restrict__ rec_J,                          \
         uint32_t* __restrict__ rec_viol, unsigned* __restrict__ rec_count, int32_t* __restrict__ rec_b
 #define IGT_SEARCH_PASS                                                                                              \
-    P, B, W, queues, work_counter, order, order_stride, ckpt, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J,    \
+    P, B, W, queues, work_counter, order, order_stride, ckpt, ck_parts, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J,    \
         part_c, rec_sN, rec_vN, rec_J, rec_viol, rec_count, rec_b
 template <int CAND, bool HI, bool VALUE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void search_fast_kernel_o3(IGT_SEARCH_ARGS) {
@@ -571,10 +573,11 @@ __global__ __launch_bounds__(64) void emit_fast_kernel(KP P, int B, int W, const
     single::rollout_pair<CAND, HI, false, false, float>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
 }
 
-// The same, from the search pass's checkpoints (small batches): four lanes per scenario roll the four quarters of the
-// winner's horizon at once -- a lone roll-out is latency, and this is a quarter of it.
+// The same, from the search pass's checkpoints (small batches): `parts` lanes per scenario roll the pieces of the
+// winner's horizon at once -- a lone roll-out is latency, and this is 1/parts of it.
 template <int CAND, bool HI>
-__global__ __launch_bounds__(64) void emit_seg_kernel(KP P, int B, int W, int Wk, const float* __restrict__ x0,
+__global__ __launch_bounds__(64) void emit_seg_kernel(KP P, int B, int W, int Wk, int parts,
+                                                      const float* __restrict__ x0,
                                                       const float* __restrict__ u_prev,
                                                       const float* __restrict__ kparams,
                                                       const uint32_t* __restrict__ flags,
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(64) void emit_seg_kernel(KP P, int B, int W, int Wk
                                                       int32_t* __restrict__ status_out, float* __restrict__ x_out,
                                                       float* __restrict__ u_out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = t / SEG_PARTS, g = t - b * SEG_PARTS;
+    const int b = t / parts, g = t - b * parts;
     if (b >= B) return;
     double bestJ = 0.0;
     int c = -1;
@@ -613,7 +616,7 @@ __global__ __launch_bounds__(64) void emit_seg_kernel(KP P, int B, int W, int Wk
     load_scenario<float>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
     int p, slot;
     candidate_slot<CAND>(P, Wk, c, p, slot);
-    const int ns = P.N / SEG_PARTS;
+    const int ns = P.N / parts;
     const size_t n_units = (size_t)B * Wk, unit = (size_t)b * Wk + p;
     const Seg seg{g * ns, (g + 1) * ns, g > 0 ? ckpt + ((size_t)(g - 1) * n_units + unit) * SEG_UNIT_DOUBLES : nullptr, slot};
     PairSink<float> sink{{xo, nullptr}, {uo, nullptr}, P.N};
@@ -621,7 +624,7 @@ __global__ __launch_bounds__(64) void emit_seg_kernel(KP P, int B, int W, int Wk
     double J[1], sN[1], vN[1];
     unsigned viol[1];
     single::rollout_pair<CAND, HI, false, false, float, PairSink<float>, false, false, true>(
-        P, S, cidx, table, cinf, sink, J, viol, sN, vN, Ckpt{nullptr, 0, 0, 0}, seg);
+        P, S, cidx, table, cinf, sink, J, viol, sN, vN, Ckpt{nullptr, 0, 0, 0, 0}, seg);
 }
 
 template <int CAND, bool HI>
@@ -877,11 +880,11 @@ static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>&
     }
     if (o3)
         hipLaunchKernelGGL((search_fast_kernel_o3<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
-                           order, order_stride, A.ckpt, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN,
+                           order, order_stride, A.ckpt, A.ck_parts, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN,
                            A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
     else
         hipLaunchKernelGGL((search_fast_kernel_o2<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
-                           order, order_stride, A.ckpt, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN,
+                           order, order_stride, A.ckpt, A.ck_parts, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN,
                            A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
     return hipGetLastError();
 }
@@ -999,7 +1002,8 @@ template <int CAND, bool HI>
 static hipError_t launch_emit_fast(const KP& P, int B, int W, const SolveArgs<float>& A, hipStream_t st) {
     if (A.ckpt) {
         const int Wk = (P.C + 127) / 128;
-        hipLaunchKernelGGL((emit_seg_kernel<CAND, HI>), dim3(((size_t)B * SEG_PARTS + 63) / 64), dim3(64), 0, st, P, B, W, Wk,
+        hipLaunchKernelGGL((emit_seg_kernel<CAND, HI>), dim3(((size_t)B * A.ck_parts + 63) / 64), dim3(64), 0, st, P, B, W, Wk,
+                           A.ck_parts,
                            A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.ckpt,
                            A.cost_out, A.argmin_out, A.status_out, A.x_out, A.u_out);
         return hipGetLastError();
