@@ -210,13 +210,12 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     const bool compact = value && sizeof(T) == 4;
     const size_t W = compact ? 1 : (value ? (size_t)p.C / 64 : ((size_t)p.C + 127) / 128);
     const size_t Wk = ((size_t)p.C + 127) / 128;          // units per scenario of the float search kernel
-    // small float batches: emit in pieces from checkpoints of the search pass (4 pieces up to B = 4096, 2 up to 6144,
-    // measured: the records cost the search pass bandwidth, the pieces save emit latency)
+    // small float batches: emit in 4 pieces from checkpoints of the search pass.  Measured (search + emit): +15 % at
+    // B = 1024, +12 % at 2048, +3 % at 4096, -1 % at 8192 -- but the records are ~150 MB of HBM writes per B = 4096 solve
+    // against ~1 MB of algorithmic traffic, so they are only spent where emit latency dominates.
     int ck_parts = 1;
-    if (sizeof(T) == 4 && B <= 6144) {
-        if (B <= 4096 && p.N % 4 == 0 && p.N >= 8) ck_parts = 4;
-        else if (p.N % 2 == 0 && p.N >= 4) ck_parts = 2;
-    }
+    if (sizeof(T) == 4 && B <= 2048 && p.N % 4 == 0 && p.N >= 8) ck_parts = 4;
+    else if (sizeof(T) == 4 && B <= 2048 && p.N % 2 == 0 && p.N >= 4) ck_parts = 2;
     if (const char* e = std::getenv("IGT_DEV_CKPT")) {
         const int v = std::atoi(e);
         if (sizeof(T) == 4 && v >= 1 && v <= igt::SEG_MAX_PARTS && p.N % v == 0 && p.N >= 2 * v) ck_parts = v;

@@ -262,7 +262,7 @@ struct Scenario {           // wave-uniform inputs of one scenario
 // Horizon checkpoints (small batches).  The search pass leaves every still-feasible candidate's state at `parts - 1`
 // evenly spaced control steps in HBM, exactly (doubles and floats as they are); emit then rolls the winner's `parts`
 // pieces of the horizon on as many lanes at once, each resuming from a checkpoint -- bit for bit the unsegmented
-// roll-out.  parts = 4 up to B = 4096, 2 up to 6144 (the records cost the search pass bandwidth), none above.
+// roll-out.  Used up to B = 2048 (the records cost the search pass bandwidth; emit latency dominates only there).
 // One unit's record: SEG_FIELDS x 128 slots x 8 B, slot = 64 q + lane of the search wave.
 //   fields 0..9: x y s ey epsi v psi J a df (double); 10: (sin,cos)(psi+beta) floats; 11: (cos,sin)(beta_{k-1}) floats
 constexpr int SEG_FIELDS = 12, SEG_SLOTS = 128, SEG_MAX_PARTS = 4;
