@@ -525,7 +525,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     search_waves<CAND, HI, VALUE, false>(IGT_SEARCH_PASS);
 }
 template <int CAND, bool HI, bool VALUE>
-__global__ __launch_bounds__(64) void search_fast_kernel_o2(IGT_SEARCH_ARGS) {    // the build that can leave checkpoints
+__global__ __launch_bounds__(64) void search_fast_kernel_o2(IGT_SEARCH_ARGS) {
+    search_waves<CAND, HI, VALUE, false>(IGT_SEARCH_PASS);
+}
+template <int CAND, bool HI, bool VALUE>
+__global__ __launch_bounds__(64) void search_fast_kernel_o2c(IGT_SEARCH_ARGS) {   // leaves horizon checkpoints (carries psi)
     search_waves<CAND, HI, VALUE, true>(IGT_SEARCH_PASS);
 }
 
@@ -882,6 +886,10 @@ static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>&
         hipLaunchKernelGGL((search_fast_kernel_o3<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
                            order, order_stride, A.ckpt, A.ck_parts, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN,
                            A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
+    else if (A.ckpt && A.ck_parts > 1)
+        hipLaunchKernelGGL((search_fast_kernel_o2c<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
+                           order, order_stride, A.ckpt, A.ck_parts, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf,
+                           A.cpar, A.part_J, A.part_c, A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
     else
         hipLaunchKernelGGL((search_fast_kernel_o2<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
                            order, order_stride, A.ckpt, A.ck_parts, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN,

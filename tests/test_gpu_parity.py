@@ -116,14 +116,19 @@ def test_solve_matches_oracle(igt, dtype, tol, eps):
         assert np.isinf(got['cost'][bad]).all() and (got['argmin'][bad] == -1).all()
 
 
-def test_search_and_emit_agree_bitwise(igt):
-    """emit re-rolls the winner with the arithmetic search used: the trajectory it stores
-    must be exactly the rollout_all trajectory of that candidate."""
-    b = _batch(64, np.float32)
-    with igt.BatchSolver(dtype='f32') as s:
+@pytest.mark.parametrize('B,cand_mode', [(64, 'lattice'), (64, 'ramp_hold'), (2304, 'lattice')])
+def test_search_and_emit_agree_bitwise(igt, B, cand_mode):
+    """emit re-rolls the winner with the arithmetic search used: the trajectory it stores must be exactly the
+    rollout_all trajectory of that candidate.  Up to B = 2048 emit resumes four quarters of the horizon from the
+    search pass's checkpoints (one lane each); above, it rolls the horizon in one piece: both must hold."""
+    b = _batch(B, np.float32)
+    with igt.BatchSolver(dtype='f32', cand_mode=cand_mode) as s:
+        s.set_cinf(*_cinf())
         sol = s.solve(*_args(b))
-        allc = s.rollout_all(*_args(b))
-    for i in range(64):
+        n = min(B, 96)
+        allc = s.rollout_all(*[a[:n] for a in _args(b)])
+    assert (sol['argmin'][:n] >= 0).sum() > n // 2
+    for i in range(n):
         c = sol['argmin'][i]
         if c >= 0:
             assert np.array_equal(sol['x'][i], allc['X'][i, c])
