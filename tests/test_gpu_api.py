@@ -256,3 +256,40 @@ def test_nan_inputs_and_determinism():
     keep[[3, 5]] = False
     for k in o1:
         assert np.array_equal(ob[k][keep], o1[k][keep], equal_nan=True)
+
+# ----------------------------------------------------------------------------- stream capture
+@pytest.mark.parametrize('B', [512, 4096])
+def test_solve_is_capturable_in_a_graph(B):
+    """The solve is a fixed sequence of stream operations (kernels, one memset node) once its workspace exists: captured
+    in a graph and replayed on new inputs written into the same buffers, it gives what the eager call gives.
+    (B = 512: queue builder + checkpointed emit; B = 4096: queue builder + plain emit.)"""
+    import torch
+    import igtmpc
+    from igtmpc.scenarios import make_batch
+    from igtmpc.cinf import cinf_halfplanes
+
+    def dev(b):
+        return [torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda()
+                for a in (b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy'])]
+
+    b1, b2 = make_batch(B, dtype=np.float32, seed=1), make_batch(B, dtype=np.float32, seed=2)
+    with igtmpc.BatchSolver(dtype='f32') as s:
+        s.set_cinf(*cinf_halfplanes())
+        bufs = dev(b1)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            out = s.solve(*bufs)                     # warm-up on the capture stream: the workspace is allocated here
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            s.solve(*bufs, out=out)
+        for dst, src in zip(bufs, dev(b2)):
+            dst.copy_(src)
+        g.replay()
+        torch.cuda.synchronize()
+        replayed = {k: v.clone() for k, v in out.items()}
+        eager = s.solve(*dev(b2))
+        torch.cuda.synchronize()
+    for k in ('x', 'u', 'cost', 'argmin', 'status'):
+        assert torch.equal(replayed[k].nan_to_num(), eager[k].nan_to_num()), k
+    assert (eager['status'] == 0).float().mean() > 0.5
