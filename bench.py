@@ -107,10 +107,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    # the exchange path can be rehearsed on one GPU with a single-rank process group (IGT_BENCH_FORCE_DIST=1 and the
+    # torchrun environment variables): same streams, events and collective calls as with N ranks
+    exchange = world > 1 or os.environ.get('IGT_BENCH_FORCE_DIST') == '1'
+    if exchange:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), rank=rank, world_size=world)
     n_gpus = world if world > 1 else 1
     dev = local_rank if world > 1 else 0
     torch.cuda.set_device(dev)
@@ -136,15 +139,39 @@ def main():
         dargs += [torch.from_numpy(batch['tv_sv']).cuda(dev), torch.from_numpy(batch['enc']).cuda(dev)]
     out = solver.solve(*dargs)
 
+    # The one exchange of the path: all-gather of the first-step controls u*[:, :, 0] so that every rank
+    # holds the full action vector.  A rank's next step does not depend on the other ranks' controls (scenarios are
+    # independent), so the exchange of step t runs on its own stream under the search pass of step t+1,
+    # double-buffered; the timed region ends with a device-wide synchronize, i.e. with every exchange complete.
+    if exchange:
+        main = torch.cuda.current_stream(dev)
+        comm = torch.cuda.Stream(dev)
+        u0_buf = [torch.empty((B, 2), dtype=torch.float32, device=f'cuda:{dev}') for _ in range(2)]
+        gathered = [torch.empty((B * world, 2), dtype=torch.float32, device=f'cuda:{dev}') for _ in range(2)]
+        ev_ready = [torch.cuda.Event() for _ in range(2)]
+        ev_free = [torch.cuda.Event() for _ in range(2)]
+        for e in ev_free:
+            e.record(comm)
+    step_no = [0]
+
     def step():
         solver.solve(*dargs, out=out)
-        if world > 1:
-            return allgather_controls(first_controls(out['u']), B_total=B * world)
+        if exchange:
+            i = step_no[0] & 1
+            step_no[0] += 1
+            main.wait_event(ev_free[i])                    # the exchange two steps back has released buffer i
+            u0_buf[i].copy_(out['u'][:, :, 0])
+            ev_ready[i].record(main)
+            with torch.cuda.stream(comm):
+                comm.wait_event(ev_ready[i])
+                dist.all_gather_into_tensor(gathered[i], u0_buf[i])
+                ev_free[i].record(comm)
+            return gathered[i]
         return None
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if exchange:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -156,7 +183,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if exchange:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f'cuda:{dev}')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -198,7 +225,7 @@ def main():
                                    f'{C} lattice candidates, 4 RK4 sub-steps, Frenet bicycle model, C_inf terminal set '
                                    f'(BASELINE configs[1])',
                        'arithmetic': 'float32 stage derivatives + float64 state accumulators, cost and verdicts',
-                       'parallelism': f'scenario shards x{n_gpus}, all-gather of u*[:, :, 0]' if n_gpus > 1 else 'single GPU',
+                       'parallelism': f'scenario shards x{n_gpus}, all-gather of u*[:, :, 0] on its own stream under the next step' if exchange else 'single GPU',
                        'cost': f'gt_mpc value net V_GT_sc{args.gt} ({len(layers) - 1} hidden layers, identity normalisation)' if args.gt else 'mpc progress cost',
                        'feasible_fraction': feasible},
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -222,7 +249,7 @@ def main():
             line['cpu_baseline'] = cpu_baseline(batch, N, C)
         print(json.dumps(line), flush=True)
     solver.close()
-    if world > 1:
+    if exchange:
         dist.barrier()
         dist.destroy_process_group()
 
