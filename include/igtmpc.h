@@ -20,7 +20,10 @@
  *     hipStreamLegacy, (void*)1, to name the legacy default stream).
  *   - state order everywhere: [x, y, s, ey, epsi, v, psi]      (mpc.py:163)
  *   - array layouts are C-contiguous with the shapes written in the comments.
- *   - one handle per (device, thread); handles share no mutable state.
+ *   - one handle per (device, thread); handles share no mutable state.  A handle owns its workspace: two solves
+ *     on one handle must not overlap in time (use one handle per stream).
+ *   - IGT_MEM_DEVICE calls only enqueue work (kernels and memset nodes; no allocation once the workspace has its
+ *     size, no host synchronisation), so after one warm-up call a solve can be captured in a stream graph.
  */
 #ifndef IGTMPC_H
 #define IGTMPC_H
