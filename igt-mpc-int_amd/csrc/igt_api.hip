@@ -120,8 +120,17 @@ int ensure_stage(igt_handle* h, size_t bytes) {
     return 0;
 }
 
+// true while `st` is recording a stream graph: nothing that synchronises or allocates may be issued then
+bool capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+
 int ensure_work(igt_handle* h, size_t bytes, hipStream_t st) {
     if (bytes <= h->work_bytes) return 0;
+    if (capturing(st))
+        return fail(IGT_E_STATE, "workspace too small for stream capture: run one eager solve of this batch size (and "
+                                 "cost / candidate mode) on this handle first");
     HIPCHK(hipStreamSynchronize(st));
     if (h->d_work) { HIPCHK(hipFree(h->d_work)); h->d_work = nullptr; h->work_bytes = 0; }
     const size_t want = bytes + bytes / 4 + 4096;
@@ -705,6 +714,7 @@ int igt_set_value_net(igt_handle* h, int32_t n_layers, const int32_t* dims, cons
     h->net_d.frag = nullptr;
     h->net_f.bout = (float)bo; h->net_f.sigma_t = (float)sigma_t; h->net_f.mu_t = (float)mu_t;
     h->net_d.bout = bo; h->net_d.sigma_t = sigma_t; h->net_d.mu_t = mu_t;
+    HIPCHK(igt::prepare_value_kernels(nm));
     h->net_set = true;
     return IGT_OK;
 }

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256) void search_kernel(KP P, int B, const T* __res
     }
 }
 
-// partials [B, W] -> cost / argmin / status (slices ordered by candidate index: strict '<' keeps the lowest)
+// partials [B, W] -> cost / argmin / status.  (J, c) is compared lexicographically: steering-ordered slices hold their
+// columns from the centre outwards, so a later slice can hold the LOWER candidate index of an exact tie
 template <typename T>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(int B, int W, const double* __restrict__ part_J,
                                                               const int32_t* __restrict__ part_c,
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(int B, int W, cons
     for (int w = 0; w < W; ++w) {
         const int cw = part_c[(size_t)b * W + w];
         const double Jw = part_J[(size_t)b * W + w];
-        if (cw >= 0 && (c < 0 || Jw < bestJ)) { bestJ = Jw; c = cw; }
+        if (cw >= 0 && (c < 0 || Jw < bestJ || (Jw == bestJ && cw < c))) { bestJ = Jw; c = cw; }
     }
     cost_out[b] = c >= 0 ? (T)bestJ : (T)INFINITY;
     argmin_out[b] = c;
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void refine_targets_kernel(KP P, int B, int W,
     for (int w = 0; w < W; ++w) {
         const int cw = part_c[(size_t)b * W + w];
         const double Jw = part_J[(size_t)b * W + w];
-        if (cw >= 0 && (c < 0 || Jw < bestJ)) { bestJ = Jw; c = cw; }
+        if (cw >= 0 && (c < 0 || Jw < bestJ || (Jw == bestJ && cw < c))) { bestJ = Jw; c = cw; }
     }
     if (c >= 0) {
         const int G = P.G, i = c / G, j = c - i * G;
@@ -548,13 +549,13 @@ __global__ __launch_bounds__(64) void emit_fast_kernel(KP P, int B, int W, const
                                                        float* __restrict__ u_out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    // final arg-min over the W slices (slices are ordered by candidate index: strict '<' keeps the lowest)
+    // final arg-min over the W slices, (J, c) lexicographic: ties -> lowest candidate index whatever the slice order
     double bestJ = 0.0;
     int c = -1;
     for (int w = 0; w < W; ++w) {
         const int cw = part_c[(size_t)b * W + w];
         const double Jw = part_J[(size_t)b * W + w];
-        if (cw >= 0 && (c < 0 || Jw < bestJ)) { bestJ = Jw; c = cw; }
+        if (cw >= 0 && (c < 0 || Jw < bestJ || (Jw == bestJ && cw < c))) { bestJ = Jw; c = cw; }
     }
     cost_out[b] = c >= 0 ? (float)bestJ : INFINITY;
     argmin_out[b] = c;
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(64) void emit_seg_kernel(KP P, int B, int W, int Wk
     for (int w = 0; w < W; ++w) {
         const int cw = part_c[(size_t)b * W + w];
         const double Jw = part_J[(size_t)b * W + w];
-        if (cw >= 0 && (c < 0 || Jw < bestJ)) { bestJ = Jw; c = cw; }
+        if (cw >= 0 && (c < 0 || Jw < bestJ || (Jw == bestJ && cw < c))) { bestJ = Jw; c = cw; }
     }
     float* xo = x_out + (size_t)b * 7 * (P.N + 1);
     float* uo = u_out + (size_t)b * 2 * P.N;
@@ -925,6 +926,23 @@ hipError_t launch_search_records<double>(const KP& P, int B, const SolveArgs<dou
     return launch_search_exact<true>(P, B, A, st);
 }
 
+// dynamic-LDS limits of the value kernels, raised once when a net is loaded (igt_set_value_net) -- not on the launch
+// path, which must stay a pure sequence of stream operations (stream capture)
+hipError_t prepare_value_kernels(int n_hidden_mats) {
+    const size_t lds_d = (size_t)VN_H * 64 * sizeof(double) * (n_hidden_mats > 1 ? 2 : 1);
+    hipError_t e = hipSuccess;
+    if (lds_d > 64 * 1024)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_kernel<double>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
+    if (e != hipSuccess) return e;
+    const size_t lds_f = (size_t)frag_floats(n_hidden_mats) * sizeof(float);
+    if (n_hidden_mats > 1)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&value_mfma_kernel<2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&value_mfma_kernel<1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+}
+
 template <typename T>
 hipError_t launch_value(const KP& P, int B, const DevNet<T>& net, const SolveArgs<T>& A, T* cost_all,
                         uint32_t* viol_all, hipStream_t st);
@@ -935,11 +953,6 @@ hipError_t launch_value<double>(const KP& P, int B, const DevNet<double>& net, c
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t lds = (size_t)VN_H * 64 * sizeof(double) * (net.n_hidden_mats > 1 ? 2 : 1);
-    if (lds > 64 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_kernel<double>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
     hipLaunchKernelGGL((value_kernel<double>), dim3((size_t)B * (P.C / 64)), dim3(64), lds, st, B, P.C, net, A.p_vec,
                        A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.part_J, A.part_c, cost_all, viol_all);
     return hipGetLastError();
@@ -951,19 +964,11 @@ hipError_t launch_value<float>(const KP& P, int B, const DevNet<float>& net, con
         CompactRecs R{A.rec_count, A.rec_b, reinterpret_cast<const int32_t*>(A.rec_viol), A.rec_sN, A.rec_vN, A.rec_J};
         // one 8-wave workgroup per CU (the weight fragments take 68 / 134 KB of its LDS), grid-stride over the list
         const size_t lds = (size_t)frag_floats(net.n_hidden_mats) * sizeof(float);
-        hipError_t e;
-        if (net.n_hidden_mats > 1) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_mfma_kernel<2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
+        if (net.n_hidden_mats > 1)
             hipLaunchKernelGGL(value_mfma_kernel<2>, dim3(A.n_cu), dim3(512), lds, st, net, R, A.tv_sv, A.enc, A.best_key);
-        } else {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_mfma_kernel<1>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
+        else
             hipLaunchKernelGGL(value_mfma_kernel<1>, dim3(A.n_cu), dim3(512), lds, st, net, R, A.tv_sv, A.enc, A.best_key);
-        }
-        e = hipGetLastError();
+        hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(keys_to_partials_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, A.best_key, A.part_J, A.part_c);
         return hipGetLastError();

@@ -148,15 +148,22 @@ class BatchSolver:
         return (L.IGT_MEM_DEVICE if torch_mode else L.IGT_MEM_HOST), ptrs, keep
 
     def _stream_ptr(self, stream, torch_mode):
+        """hipStream_t for the C ABI.  Device mode: the given stream, else torch's current stream.  torch's default
+        stream has handle 0, which the C ABI reads as "the handle's own non-blocking stream" -- the kernels would
+        then be unordered with the torch ops that produce their inputs and consume their outputs.  So in device
+        mode ANY resolved handle of 0 (implicit, `stream=torch.cuda.default_stream()`, `stream=0`) names the legacy
+        default stream explicitly (hipStreamLegacy == (hipStream_t)1).  Host mode keeps NULL: the library stages
+        and synchronises on its own stream."""
         if stream is not None:
-            return getattr(stream, 'cuda_stream', stream)
-        if torch_mode:
+            ptr = int(getattr(stream, 'cuda_stream', stream) or 0)
+        elif torch_mode:
             import torch
-            # torch's default stream has handle 0, which the C ABI reads as "the handle's own stream":
-            # name the legacy default stream explicitly (hipStreamLegacy == (hipStream_t)1) so the
-            # kernels are ordered with the surrounding torch ops
-            return torch.cuda.current_stream(self.device).cuda_stream or 1
-        return None
+            ptr = int(torch.cuda.current_stream(self.device).cuda_stream or 0)
+        else:
+            return None
+        if torch_mode and ptr == 0:
+            ptr = 1
+        return ptr or None
 
     # ------------------------------------------------------------------ the solve
     def solve(self, x0, u_prev, kparams, flags, obs_xy=None, tv_sv=None, enc=None, out=None, stream=None):

@@ -293,3 +293,91 @@ def test_solve_is_capturable_in_a_graph(B):
     for k in ('x', 'u', 'cost', 'argmin', 'status'):
         assert torch.equal(replayed[k].nan_to_num(), eager[k].nan_to_num()), k
     assert (eager['status'] == 0).float().mean() > 0.5
+
+
+@pytest.mark.parametrize('how', ['default_stream_object', 'zero', 'implicit'])
+def test_explicit_default_stream_is_ordered_with_torch_ops(how):
+    """An explicitly passed default stream (handle 0) must mean torch's legacy default stream, not the handle's own
+    non-blocking stream: the solve is enqueued right after an in-place update of its inputs on that stream and read
+    right after it, without any synchronisation in between; it must see the update and be seen by the read."""
+    import torch
+    import igtmpc
+    from igtmpc.scenarios import make_batch
+    from igtmpc.cinf import cinf_halfplanes
+    B = 4096
+    b1, b2 = make_batch(B, dtype=np.float32, seed=3), make_batch(B, dtype=np.float32, seed=4)
+    keys = ('x0', 'u_prev', 'kparams', 'flags', 'obs_xy')
+    T = lambda a: torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a)
+    with igtmpc.BatchSolver(dtype='f32') as s:
+        s.set_cinf(*cinf_halfplanes())
+        want = s.solve(*[b2[k] for k in keys])                      # host mode: synchronous reference result
+        bufs = [T(b1[k]).cuda() for k in keys]
+        out = s.solve(*bufs)                                        # workspace allocation + warm-up
+        torch.cuda.synchronize()
+        staged = [T(b2[k]).pin_memory() for k in keys]
+        stream = {'default_stream_object': torch.cuda.default_stream(), 'zero': 0, 'implicit': None}[how]
+        # a long-running producer on the default stream, then the in-place input update, then the solve
+        junk = torch.randn(4096, 4096, device='cuda')
+        for _ in range(8):
+            junk = junk @ junk * 1e-3
+        for dst, src in zip(bufs, staged):
+            dst.copy_(src, non_blocking=True)
+        s.solve(*bufs, out=out, stream=stream)
+        got = {k: v.clone() for k, v in out.items()}                # consumer on the default stream, no sync before
+        torch.cuda.synchronize()
+    for k in ('x', 'u', 'cost', 'argmin', 'status'):
+        assert np.array_equal(got[k].cpu().numpy(), want[k], equal_nan=True), (how, k)
+
+
+def test_value_net_solve_is_capturable_and_growth_under_capture_fails_loudly(golden_dir):
+    """gt_mpc solve (search + MFMA value kernel + atomicMin winner + emit) captured in a graph == eager; and a solve
+    that would have to GROW the workspace while the stream is capturing returns IGT_E_STATE instead of synchronising
+    a capturing stream (which would invalidate the capture with an opaque HIP error)."""
+    import torch
+    import igtmpc
+    from igtmpc.scenarios import make_batch
+    from igtmpc.cinf import cinf_halfplanes
+    v = np.load(f'{golden_dir}/value_net_golden.npz')
+    layers, i = [], 0
+    while f'sc3_W{i}' in v:
+        layers.append((v[f'sc3_W{i}'], v[f'sc3_b{i}']))
+        i += 1
+    keys = ('x0', 'u_prev', 'kparams', 'flags', 'obs_xy', 'tv_sv', 'enc')
+
+    def dev(b, n=None):
+        return [torch.from_numpy(b[k].view(np.int32) if b[k].dtype == np.uint32 else b[k])[:n].contiguous().cuda()
+                for k in keys]
+
+    B = 4096
+    b1, b2 = make_batch(B, dtype=np.float32, seed=1), make_batch(B, dtype=np.float32, seed=2)
+    with igtmpc.BatchSolver(dtype='f32', cost_mode='value_net') as s:
+        s.set_cinf(*cinf_halfplanes())
+        s.set_value_net(layers)
+        side = torch.cuda.Stream()
+        small = dev(b1, 256)
+        with torch.cuda.stream(side):
+            out_small = s.solve(*small)              # workspace sized for B = 256 only
+        side.synchronize()
+        bufs = dev(b1)
+        out = {k: torch.empty((B,) + tuple(t.shape[1:]), dtype=t.dtype, device='cuda') for k, t in out_small.items()}
+        g0 = torch.cuda.CUDAGraph()
+        with pytest.raises(igtmpc.IgtError, match='workspace too small for stream capture'):
+            with torch.cuda.graph(g0, stream=side):
+                s.solve(*bufs, out=out)
+        del g0
+        with torch.cuda.stream(side):
+            s.solve(*bufs, out=out)                  # eager warm-up at the real size
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            s.solve(*bufs, out=out)
+        for dst, src in zip(bufs, dev(b2)):
+            dst.copy_(src)
+        g.replay()
+        torch.cuda.synchronize()
+        replayed = {k: t.clone() for k, t in out.items()}
+        eager = s.solve(*dev(b2))
+        torch.cuda.synchronize()
+    for k in ('x', 'u', 'cost', 'argmin', 'status'):
+        assert torch.equal(replayed[k].nan_to_num(), eager[k].nan_to_num()), k
+    assert (eager['status'] == 0).float().mean() > 0.5

@@ -1,0 +1,121 @@
+"""-m gpu : the HIP path at BASELINE.json's FULL configuration sizes, through the C ABI.
+
+  configs[2]  batch = 65 536 scenarios (all 8 sc variants tiled), horizon 20, Frenet model
+  configs[3]  262 144 scenarios sharded 8 ways  -> the shard one GPU solves: 32 768 (rank 3's block here)
+  configs[4]  gt_mpc: batch = 65 536 with the terminal value network in the cost
+
+The oracle's full [B, C, 7, N+1] tensor would be ~20 GB at these sizes, so each test
+  (1) compares a FIXED 512-scenario subsample taken from inside the big batch's result with the float64
+      oracle run on exactly those scenarios (f64: 1e-9, f32: 1e-5, arg-min / status exact where the decision
+      is not inside float noise), and
+  (2) checks over the WHOLE batch the size-independent property the domain offers: scenarios are independent,
+      so the big batch must equal the same scenarios solved in pieces, bit for bit.
+"""
+import numpy as np
+import pytest
+
+import np_oracle as O
+from helpers import REL_TOL, ambiguous_mask, oracle_params, rel_err
+
+pytestmark = pytest.mark.gpu
+
+ARGS = ('x0', 'u_prev', 'kparams', 'flags', 'obs_xy')
+
+
+@pytest.fixture(scope='module')
+def igt():
+    import igtmpc
+    igtmpc.load_library()
+    return igtmpc
+
+
+def _cinf():
+    from igtmpc.cinf import cinf_halfplanes
+    return cinf_halfplanes()
+
+
+def _net(golden_dir, sc):
+    v = np.load(f'{golden_dir}/value_net_golden.npz')
+    layers, i = [], 0
+    while f'sc{sc}_W{i}' in v:
+        layers.append((v[f'sc{sc}_W{i}'], v[f'sc{sc}_b{i}']))
+        i += 1
+    return layers
+
+
+def _check_subsample(b, got, idx, P, tol, eps, net=None):
+    """got[idx] against the float64 oracle on the same 512 scenarios."""
+    f = lambda k: np.asarray(b[k][idx], dtype=np.float64)
+    kw = {}
+    if net is not None:
+        kw = dict(net=net, tv_sv=f('tv_sv'), enc=f('enc'))
+    ref = O.solve_batch(f('x0'), f('u_prev'), f('kparams'), b['flags'][idx], f('obs_xy'), *_cinf(), P,
+                        return_all=True, **kw)
+    kp = f('kparams')[:, None, :]
+    x0 = O.apply_flags(f('x0'), b['flags'][idx])[:, None, :]
+    bp = O.breakpoint_distance(x0, ref['U'], kp, P)
+    amb = ambiguous_mask(ref, P, eps, eps, eps, bp)
+    ok = ~amb
+    assert ok.mean() > 0.9, f'only {ok.mean():.3f} of the subsample is decided outside float noise'
+    g = {k: got[k][idx] for k in ('x', 'u', 'cost', 'argmin', 'status')}
+    assert (g['status'][ok] == ref['status'][ok]).all()
+    assert (g['argmin'][ok] == ref['argmin'][ok]).all()
+    sol = ok & (ref['status'] == 0)
+    assert sol.sum() > 100, 'subsample has too few solvable scenarios to mean anything'
+    assert rel_err(g['x'][sol], ref['x'][sol]).max() <= tol
+    assert rel_err(g['u'][sol], ref['u'][sol]).max() <= max(tol, 1e-7)
+    assert rel_err(g['cost'][sol], ref['cost'][sol]).max() <= tol
+    return float(amb.mean())
+
+
+def _check_pieces(solver, b, big, cuts, extra=()):
+    """big batch == the same scenarios solved in pieces (different queue make-up, other search build), bitwise."""
+    keys = list(ARGS) + list(extra)
+    parts = [solver.solve(*[np.ascontiguousarray(b[k][lo:hi]) for k in keys]) for lo, hi in zip(cuts[:-1], cuts[1:])]
+    for k in ('x', 'u', 'cost', 'argmin', 'status'):
+        assert np.array_equal(np.concatenate([q[k] for q in parts]), big[k], equal_nan=True), k
+
+
+def _run(igt, B, offset, dtype, tol, eps, golden_dir=None, gt_sc=0):
+    from igtmpc.scenarios import make_batch
+    npdt = np.float64 if dtype == 'f64' else np.float32
+    b = make_batch(B, dtype=npdt, offset=offset)
+    assert set(np.unique(b['sc'])) == set(range(1, 9)), 'all 8 scenario variants must be tiled into the batch'
+    idx = np.sort(np.random.default_rng(7).choice(B, 512, replace=False))
+    kw, extra, net = {}, (), None
+    if gt_sc:
+        layers = _net(golden_dir, gt_sc)
+        net = dict(layers=layers, Wn=np.eye(6), mu_f=np.zeros(6), sigma_t=1.0, mu_t=0.0)   # bench.py's normalisation
+        kw = dict(cost_mode='value_net')
+        extra = ('tv_sv', 'enc')
+    with igt.BatchSolver(dtype=dtype, **kw) as s:
+        P = oracle_params(s)
+        s.set_cinf(*_cinf())
+        if gt_sc:
+            s.set_value_net(**net)
+        big = s.solve(*[b[k] for k in list(ARGS) + list(extra)])
+        assert 0.5 < (big['status'] == 0).mean() < 1.0
+        q = B // 4
+        _check_pieces(s, b, big, [0, 4096, 4096 + 1003, q + 17, 2 * q, 3 * q + 5, B], extra)
+    amb = _check_subsample(b, big, idx, P, tol, eps, net)
+    print(f'B={B} dtype={dtype} gt={gt_sc}: ambiguous share of the subsample {amb:.4f}')
+
+
+@pytest.mark.parametrize('dtype,tol,eps', [('f64', 1e-9, 1e-9), ('f32', REL_TOL, 2e-5)])
+def test_config2_batch_65536(igt, dtype, tol, eps):
+    """BASELINE configs[2]: batch = 65 536, all 8 sc variants tiled, horizon 20, Frenet-frame model."""
+    _run(igt, 65536, 0, dtype, tol, eps)
+
+
+@pytest.mark.parametrize('dtype,tol,eps', [('f64', 1e-9, 1e-9), ('f32', REL_TOL, 2e-5)])
+def test_config3_shard_32768(igt, dtype, tol, eps):
+    """BASELINE configs[3]: 262 144 scenarios sharded 8 ways = 32 768 per GPU; rank 3's shard (offset 3 x 32 768,
+    the generator's per-rank offset path).  The all-gather across ranks is covered by tests/test_sharding_gloo.py."""
+    _run(igt, 32768, 3 * 32768, dtype, tol, eps)
+
+
+@pytest.mark.parametrize('dtype,tol,eps,sc', [('f64', 1e-9, 1e-9, 1), ('f32', REL_TOL, 2e-5, 1), ('f32', REL_TOL, 2e-5, 3)])
+def test_config4_gt_mpc_65536(igt, golden_dir, dtype, tol, eps, sc):
+    """BASELINE configs[4]: gt_mpc, terminal value network (shipped V_GT_sc1: 2 hidden layers, V_GT_sc3: 3) evaluated
+    on the GPU inside the cost, batch = 65 536 (per GPU; the 8-GPU run itself is the driver's)."""
+    _run(igt, 65536, 0, dtype, tol, eps, golden_dir, sc)

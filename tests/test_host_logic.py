@@ -166,3 +166,34 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     import igtmpc
     with pytest.raises(ImportError):
         igtmpc.BatchSolver()
+
+
+# ----------------------------------------------------------------------------- bench.py launch path (no GPU needed)
+def _run_bench(*argv, env_extra=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, 'bench.py'), *argv], env=env, capture_output=True,
+                          text=True, timeout=240)
+
+
+def test_bench_gpus_2_without_torchrun_variables_spawns_two_ranks():
+    """`python bench.py --gpus 2` with no torchrun variables must start 2 ranks itself (never silently run one):
+    rehearsed on CPU over gloo -- the ranks meet, all-gather a token, and rank 0 reports what it saw."""
+    import json
+    r = _run_bench('--gpus', '2', '--rehearse-cpu')
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['ranks_seen'] == 2 and line['tokens'] == [0, 1] and line['spawned_by_bench'] is True
+
+
+def test_bench_refuses_a_multi_gpu_line_it_cannot_measure():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('needs a host with fewer than 2 GPUs')
+    r = _run_bench('--gpus', '2')
+    assert r.returncode != 0 and 'refusing' in r.stderr and not r.stdout.strip()
+    r = _run_bench('--gpus', '2', env_extra={'WORLD_SIZE': '4', 'RANK': '0'})      # launcher and flag disagree
+    assert r.returncode != 0 and 'WORLD_SIZE=4' in r.stderr
