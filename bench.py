@@ -34,6 +34,7 @@ sys.path.insert(0, os.path.join(ROOT, 'igt-mpc-int_amd'))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SIMDS = 256 * 4                # 256 CUs x 4 SIMDs
 VALU_ISSUE_CYCLES = 4          # a wave64 VALU instruction occupies its SIMD's 16 lanes for 4 cycles
+PEAK_CLOCK_GHZ = 2.4           # MI355X_MICROARCH.md: peak engine clock (the issue capacity the fraction is taken of)
 N_HORIZON, N_CAND = 20, 256
 
 
@@ -346,10 +347,10 @@ def main():
                               f'{tj.get("source_hash")}; not measured by this run)'
             except Exception:
                 traffic, valu_insts, pmc_src = None, None, None
-        clk_ghz = torch.cuda.get_device_properties(dev).clock_rate / 1e6
+        clk_ghz = PEAK_CLOCK_GHZ
         valu = {'bound': 'valu_issue', 'unit': 'fraction of SIMD issue cycles',
                 'definition': 'VALU wave-instructions per launch x 4 issue cycles / (1024 SIMDs x kernel cycles); kernel '
-                              'cycles = live kernel_ms x shader clock',
+                              'cycles = live kernel_ms x peak shader clock',
                 'valu_instructions_per_launch': valu_insts, 'kernel_ms': search_ms, 'shader_clock_ghz': clk_ghz,
                 'achieved': None, 'peak': 1.0, 'frac': None, 'source': pmc_src}
         if valu_insts:

@@ -155,8 +155,8 @@ struct Arena {   // carves 256-byte aligned pieces out of the staging buffer
 };
 
 // the queue builder of small float batches zeroes the search kernel's unit counters itself
-inline bool counters_by_builder(const igt::KP& kp, int B, const igt::SolveArgs<float>& A) { return igt::search_builds_queues(kp, B, A); }
-inline bool counters_by_builder(const igt::KP&, int, const igt::SolveArgs<double>&) { return false; }
+template <typename T>
+inline bool counters_by_builder(const igt::KP& kp, int B, const igt::SolveArgs<T>& A) { return igt::search_builds_queues(kp, B, A); }
 
 template <typename T>
 int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* kparams, const uint32_t* flags,
@@ -217,8 +217,10 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     // per-scenario partials: float value path reduces to ONE per scenario (compact list + atomicMin),
     // double value path keeps one per 64-candidate chunk, progress cost one per 128-candidate slice
     const bool compact = value && sizeof(T) == 4;
-    const size_t W = compact ? 1 : (value ? (size_t)p.C / 64 : ((size_t)p.C + 127) / 128);
-    const size_t Wk = ((size_t)p.C + 127) / 128;          // units per scenario of the float search kernel
+    // units per scenario of the search kernel: 128-candidate slices (float, two candidates per lane) or 64 (double)
+    const size_t Wk = sizeof(T) == 4 ? ((size_t)p.C + 127) / 128 : (size_t)p.C / 64;
+    const size_t W = compact ? 1 : (value ? (size_t)p.C / 64 : Wk);
+    const bool exact64 = sizeof(T) == 8 && (h->kp.dev & 1024);      // developer switch: oracle-order double kernels
     // small float batches: emit in 4 pieces from checkpoints of the search pass.  Measured (search + emit): +15 % at
     // B = 1024, +12 % at 2048, +3 % at 4096, -1 % at 8192 -- but the records are ~150 MB of HBM writes per B = 4096 solve
     // against ~1 MB of algorithmic traffic, so they are only spent where emit latency dominates.
@@ -250,7 +252,7 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
         A.ck_parts = ck_parts;
         // small batches: the search queues are sorted longest unit first (build_queues_kernel; 3-5 % up to B = 4096,
         // nothing from 8192 on)
-        A.queue_order = (sizeof(T) == 4 && B <= 6144) ? wa.take<unsigned>((size_t)((B + 7) / 8) * 8 * Wk) : nullptr;
+        A.queue_order = B <= 6144 ? wa.take<unsigned>((size_t)((B + 7) / 8) * 8 * Wk) : nullptr;
         if (value) {
             A.rec_J = wa.take<double>(n_rec);
             A.rec_sN = wa.take<T>(n_rec);
@@ -273,17 +275,18 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
                 HIPCHK(hipMemsetAsync(A.rec_count, 0, 256, st));
                 HIPCHK(hipMemsetAsync(A.best_key, 0xff, (size_t)B * 8, st));
             }
+            else if (!exact64 && !counters_by_builder(kp, B, A)) HIPCHK(hipMemsetAsync(A.work_counter, 0, 8 * 256, st));
             HIPCHK(igt::launch_search_records<T>(kp, B, A, st));
             HIPCHK(igt::launch_value<T>(kp, B, net_of<T>(h), A, nullptr, nullptr, st));
-            if (sizeof(T) == 8) HIPCHK(igt::launch_reduce<T>(B, (int)W, A, st));
+            if (exact64) HIPCHK(igt::launch_reduce<T>(B, (int)W, A, st));
         } else {
-            if (sizeof(T) == 4 && !counters_by_builder(kp, B, A)) HIPCHK(hipMemsetAsync(A.work_counter, 0, 8 * 256, st));
+            if (!exact64 && !counters_by_builder(kp, B, A)) HIPCHK(hipMemsetAsync(A.work_counter, 0, 8 * 256, st));
             HIPCHK(igt::launch_search<T>(kp, B, A, h->nc, st));
         }
         if (it < p.refine_iters) {   // winner of this pass -> centre / span of the next one
             igt::SolveArgs<T> R = A;
             int Wr = (int)W;
-            if (sizeof(T) == 8 && !value) {   // double path, progress cost: the search already reduced to one winner
+            if (exact64 && !value) {   // oracle-order double kernels, progress cost: the search already reduced to one winner
                 R.part_J = reinterpret_cast<double*>(A.cost_out);
                 R.part_c = A.argmin_out;
                 Wr = 1;

@@ -1,0 +1,404 @@
+// igt_fast64.h -- the float64 rollout of the search / emit / rollout-all kernels of the _f64 entry points (gfx950).
+//
+// The reference is float64 end to end (kinematic_bicycle_model_frenet.py:70-127, mpc.py:356-373), so this is the path
+// that runs at the reference's precision.  It evaluates the same RK4 stages as ExactStepper<double> (igt_device.h,
+// the oracle's operation order) but with the algebra of the float path (igt_fast_impl.inc) carried out in double:
+//   * v and psi do not feed back: stage speeds and the psi offsets are closed-form;
+//   * sin/cos of (beta+epsi') and (psi'+beta) are rotations of the sub-step's base pair by the stage offset, the
+//     offset's sine / cosine from a Taylor polynomial (|offset| <= h |rate| << 1; truncation < 1e-17 relative);
+//     libm-grade sincos is evaluated once per control step (df, epsi) instead of 32 times;
+//   * all weighted stage sums are factorised, sum_j w_j g_j cos(theta + d_j) = cos(theta) A - sin(theta) B, for the
+//     Frenet rows and the Cartesian rows (the latter including the reference's quirk that stage 4 sees
+//     psi + h/2 k3[6], kinematic_bicycle_model_frenet.py:111);
+//   * beta = atan(r tan df) is never formed: cos(beta) = c/n, sin(beta) = r s/n, n = sqrt(c^2 + r^2 s^2);
+//   * K(s') is decided on (s - b) + offset >= 0 (the oracle compares s + offset >= b).
+// Nothing is approximated beyond double rounding: measured <= 1e-12 against the reference-generated golden
+// rollouts (curvature break-point straddlers included), i.e. three orders inside the 1e-9 bar of the _f64 tests.
+// Three variants of a sub-step (K == 0 everywhere / K == kv everywhere / general), chosen by wave votes on a travel
+// bound, are bit-identical wherever they apply (x - 0, x * 1, rotation by (0, 1) are exact), so search (votes),
+// emit (general variant, lanes of different scenarios) and rollout-all agree bit for bit -- asserted in the tests.
+#pragma once
+#include "igt_device.h"
+
+namespace igt {
+namespace f64 {
+
+// ---- libm-grade sin/cos, used once per control step ------------------------------------------------------------
+// minimax kernels on |r| <= pi/4 (the classical fdlibm coefficient sets), ~1 ulp
+__device__ __forceinline__ void sincos_kernel(double r, double& s, double& c) {
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    s = fma(r * z, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    c = fma(z * z, pc, fma(z, -0.5, 1.0));
+}
+// any |x| up to ~1e6: two-term Cody-Waite reduction to |r| <= pi/4
+__device__ __forceinline__ void sincos_reduced(double x, double& s, double& c) {
+    const double kd = __builtin_rint(x * 0.63661977236758134);                   // 2/pi
+    double r = fma(-kd, 1.5707963267948966, x);
+    r = fma(-kd, 6.123233995736766e-17, r);
+    const int q = (int)kd;
+    double sr, cr;
+    sincos_kernel(r, sr, cr);
+    const double a = (q & 1) ? cr : sr;
+    const double b = (q & 1) ? sr : cr;
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
+}
+constexpr double QUADRANT0 = 0.78;     // < pi/4: sincos_reduced() has kd = 0 there, so the kernel alone agrees bit for bit
+
+// ---- sin/cos of a small stage offset ---------------------------------------------------------------------------
+// |d| <= 0.15: sin to d^9, cos to d^10 (first dropped terms 2e-17 / 2e-19 relative to 1)
+__device__ __forceinline__ void small_sincos(double d, double& sd, double& cd) {
+    const double d2 = d * d;
+    double p = fma(d2, 1.0 / 362880.0, -1.0 / 5040.0);
+    p = fma(d2, p, 1.0 / 120.0);
+    p = fma(d2, p, -1.0 / 6.0);
+    sd = fma(d * d2, p, d);
+    double q = fma(d2, -1.0 / 3628800.0, 1.0 / 40320.0);
+    q = fma(d2, q, -1.0 / 720.0);
+    q = fma(d2, q, 1.0 / 24.0);
+    q = fma(d2, q, -0.5);
+    cd = fma(d2, q, 1.0);
+}
+// |d| <= 0.6 (coarse discretisations, n_rk4 <= 2): two more terms each
+__device__ __forceinline__ void small_sincos_hi(double d, double& sd, double& cd) {
+    const double d2 = d * d;
+    double p = fma(d2, 1.0 / 6227020800.0, -1.0 / 39916800.0);
+    p = fma(d2, p, 1.0 / 362880.0);
+    p = fma(d2, p, -1.0 / 5040.0);
+    p = fma(d2, p, 1.0 / 120.0);
+    p = fma(d2, p, -1.0 / 6.0);
+    sd = fma(d * d2, p, d);
+    double q = fma(d2, -1.0 / 87178291200.0, 1.0 / 479001600.0);
+    q = fma(d2, q, -1.0 / 3628800.0);
+    q = fma(d2, q, 1.0 / 40320.0);
+    q = fma(d2, q, -1.0 / 720.0);
+    q = fma(d2, q, 1.0 / 24.0);
+    q = fma(d2, q, -0.5);
+    cd = fma(d2, q, 1.0);
+}
+
+__device__ __forceinline__ void rotate(double& s, double& c, double sd, double cd) {
+    const double s_ = fma(s, cd, c * sd);
+    const double c_ = fma(c, cd, -(s * sd));
+    s = s_; c = c_;
+}
+// 1/x: hardware estimate + two Newton steps (x = 1 gives exactly 1, which the K == 0 identities rely on)
+__device__ __forceinline__ double rcp_nr(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+template <bool HI_ORDER>
+struct Fast64 {
+    double h, hh, h6, kv, inv_lr, lr_ratio, b0, b1, dt;
+    int n_rk4;
+
+    __device__ __forceinline__ void init(const KP& P, double b0_, double b1_, double kv_) {
+        h = P.h; hh = P.h / 2; h6 = P.h / 6;
+        kv = kv_; inv_lr = 1.0 / P.l_r; lr_ratio = P.lr_ratio;
+        b0 = b0_; b1 = b1_; dt = P.dt; n_rk4 = P.n_rk4;
+    }
+    static __device__ __forceinline__ void ssc(double d, double& sd, double& cd) {
+        if (HI_ORDER) small_sincos_hi(d, sd, cd); else small_sincos(d, sd, cd);
+    }
+    // curvature at the break-point-relative argument d + o  (mpc.py:199 pw_const: kv [s >= b0] - kv [s >= b1])
+    __device__ __forceinline__ double curv(double d0, double d1, double o) const {
+        return ((d0 + o >= 0.0) ? kv : 0.0) - ((d1 + o >= 0.0) ? kv : 0.0);
+    }
+
+    // working set of one control step: base pairs (s1,c1) = (sin,cos)(beta+epsi), (s2,c2) = (sin,cos)(psi+beta);
+    // v1, ey and the break-point-relative arc lengths d0, d1 advance per sub-step; acc_* are the step's increments
+    struct Work {
+        double s1, c1, s2, c2, v1, ey, d0, d1, acc_s, acc_ey, acc_ep, acc_x, acc_y, acc_psi;
+    };
+
+    // A = g1 + 2 g2 cdA + 2 g3 cdB + g4 cdC,  B = 2 g2 sdA + 2 g3 sdB + g4 sdC   (weights 1,2,2,1)
+    static __device__ __forceinline__ void stage_sums(double g1, double g2, double g3, double g4, double sdA, double cdA,
+                                                      double sdB, double cdB, double sdC, double cdC, double& A, double& B) {
+        const double t2 = 2.0 * g2, t3 = 2.0 * g3;
+        A = fma(g4, cdC, fma(t3, cdB, fma(t2, cdA, g1)));
+        B = fma(g4, sdC, fma(t3, sdB, t2 * sdA));
+    }
+
+    // MODE 0: general (K decided per stage argument); 1: K == 0 at every stage argument of every lane; 2: every stage
+    // argument of every lane lies strictly inside the arc, K == kv.  All three give identical bits where they apply.
+    template <int MODE>
+    __device__ __forceinline__ void substep(double ha, double sblr, Work& w) const {
+        constexpr bool K0 = MODE == 1, KC = MODE == 2;
+        const double v1 = w.v1;
+        const double v2 = v1 + ha;            // stages 2,3
+        const double v4 = v2 + ha;            // stage 4
+        const double s1 = w.s1, c1 = w.c1;
+        const double w1 = v1 * sblr, w2 = v2 * sblr, w4 = v4 * sblr;
+        // psi offsets h/2 w1 (stage 2), h/2 w2 (stages 3 AND 4, frenet.py:111)
+        double sd2, cd2, sd3, cd3;
+        ssc(hh * w1, sd2, cd2);
+        ssc(hh * w2, sd3, cd3);
+        double As, Bs, Ae, Be, ip, sdC, cdC, sdP, cdP;
+        if (K0) {
+            // 1 - K ey = 1 and depsi = dpsi: the (beta+epsi) stage offsets are the psi offsets, the gains the speeds
+            ssc(h * w2, sdP, cdP);
+            sdC = sdP; cdC = cdP;
+            stage_sums(v1, v2, v2, v4, sd2, cd2, sd3, cd3, sdC, cdC, Ae, Be);
+            As = Ae; Bs = Be;
+            ip = h * w2;
+        } else {
+            const double ey = w.ey, d0 = w.d0, d1 = w.d1;
+            double sdA, cdA, sdB, cdB, sa, ca;
+            // ---- stage 1                                                            (frenet.py:73-79)
+            double K = KC ? kv : curv(d0, d1, 0.0);
+            const double g1 = v1 * rcp_nr(fma(-K, ey, 1.0));
+            const double ds1 = g1 * c1;
+            const double de1 = v1 * s1;
+            const double kd1 = ds1 * K;
+            const double dp1 = w1 - kd1;
+            // ---- stage 2: arguments base + h/2 k1
+            ssc(hh * dp1, sdA, cdA);
+            sa = s1; ca = c1; rotate(sa, ca, sdA, cdA);
+            if (!KC) K = curv(d0, d1, hh * ds1);
+            const double g2 = v2 * rcp_nr(fma(-K, fma(hh, de1, ey), 1.0));
+            const double ds2 = g2 * ca;
+            const double de2 = v2 * sa;
+            const double kd2 = ds2 * K;
+            const double dp2 = w2 - kd2;
+            // ---- stage 3: base + h/2 k2
+            ssc(hh * dp2, sdB, cdB);
+            sa = s1; ca = c1; rotate(sa, ca, sdB, cdB);
+            if (!KC) K = curv(d0, d1, hh * ds2);
+            const double g3 = v2 * rcp_nr(fma(-K, fma(hh, de2, ey), 1.0));
+            const double ds3 = g3 * ca;
+            const double de3 = v2 * sa;
+            const double kd3 = ds3 * K;
+            const double dp3 = w2 - kd3;
+            // ---- stage 4: base + h k3 (only its cosine is needed individually, for depsi)
+            ssc(h * dp3, sdC, cdC);
+            if (!KC) K = curv(d0, d1, h * ds3);
+            const double g4 = v4 * rcp_nr(fma(-K, fma(h, de3, ey), 1.0));
+            const double ds4 = g4 * fma(c1, cdC, -(s1 * sdC));
+            const double kd4 = ds4 * K;
+            stage_sums(g1, g2, g3, g4, sdA, cdA, sdB, cdB, sdC, cdC, As, Bs);
+            stage_sums(v1, v2, v2, v4, sdA, cdA, sdB, cdB, sdC, cdC, Ae, Be);
+            ssc(h * w2, sdP, cdP);
+            const double corr = h6 * (kd1 + 2.0 * kd2 + 2.0 * kd3 + kd4);
+            ip = h * w2 - corr;
+        }
+        // ---- Frenet increments (frenet.py:113-115)
+        const double is = h6 * fma(c1, As, -(s1 * Bs));
+        const double ie = h6 * fma(s1, Ae, c1 * Be);
+        // ---- Cartesian rows collapse to one rotation of (A,B) as well (stage 4 shares stage 3's offset)
+        const double v34 = fma(2.0, v2, v4);
+        const double tv2 = 2.0 * v2;
+        const double Ac = fma(v34, cd3, fma(tv2, cd2, v1));
+        const double Bc = fma(v34, sd3, tv2 * sd2);
+        w.acc_x = fma(h6, fma(w.c2, Ac, -(w.s2 * Bc)), w.acc_x);
+        w.acc_y = fma(h6, fma(w.s2, Ac, w.c2 * Bc), w.acc_y);
+        w.acc_psi = fma(h6, w1 + 4.0 * w2 + w4, w.acc_psi);
+        w.acc_s += is; w.acc_ey += ie; w.acc_ep += ip;
+        w.d0 += is; w.d1 += is; w.ey += ie; w.v1 = v4;
+        // ---- base pairs for the next sub-step: (psi+beta) advances by h w2, (beta+epsi) by ip = h w2 - corr.
+        // K == 0: corr = 0 exactly and ip = h w2 - 0, so ssc(ip) IS (sdP, cdP) -- the variants stay bit-identical.
+        rotate(w.s2, w.c2, sdP, cdP);
+        if (K0) {
+            rotate(w.s1, w.c1, sdP, cdP);
+        } else {
+            double sd, cd;
+            ssc(ip, sd, cd);
+            rotate(w.s1, w.c1, sd, cd);
+        }
+    }
+
+    // n_rk4 sub-steps of one control step.  The K == 0 variant (or the K == kv one) is taken when it is provably
+    // exact for every active lane of the wave: straight route, or every lane's stage arguments stay outside (inside)
+    // the arc [b0, b1] by the travel bound |ds| <= 2 |v| (1/(1 - K ey) < 2 for any state near the road).
+    // UNIFORM = false (emit: the lanes of a wave belong to different scenarios): general variant only.
+    template <bool UNIFORM>
+    __device__ __forceinline__ void substeps(double a, double sblr, Work& w) const {
+        const double ha = hh * a;
+        if (!UNIFORM) {
+            for (int j = 0; j < n_rk4; ++j) substep<0>(ha, sblr, w);
+            return;
+        }
+        if (kv == 0.0) {                       // straight route: scalar condition, hoisted
+            for (int j = 0; j < n_rk4; ++j) substep<1>(ha, sblr, w);
+            return;
+        }
+        {   // the whole control step: |travel| <= 2 dt (|v| + dt |a|)
+            const double m = (2.0 * dt) * (fabs(w.v1) + dt * fabs(a));
+            const bool clear = (w.d0 + m < 0.0) | (w.d1 - m > 0.0);
+            const bool inside = (w.d0 - m > 0.0) & (w.d1 + m < 0.0);
+            if (__all(clear)) {
+                for (int j = 0; j < n_rk4; ++j) substep<1>(ha, sblr, w);
+                return;
+            }
+            if (__all(inside)) {
+                for (int j = 0; j < n_rk4; ++j) substep<2>(ha, sblr, w);
+                return;
+            }
+        }
+        for (int j = 0; j < n_rk4; ++j) {
+            // travel bound of this sub-step: |o| <= h |ds| <= 2 h (|v| + |h a|)
+            const double m = (2.0 * h) * (fabs(w.v1) + 2.0 * fabs(ha));
+            const bool clear = (w.d0 + m < 0.0) | (w.d1 - m > 0.0);
+            const bool inside = (w.d0 - m > 0.0) & (w.d1 + m < 0.0);
+            if (__all(clear)) substep<1>(ha, sblr, w);
+            else if (__all(inside)) substep<2>(ha, sblr, w);
+            else substep<0>(ha, sblr, w);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// one pass over ONE candidate per lane
+// ---------------------------------------------------------------------------------------
+// CAND = CAND_LATTICE / CAND_RAMP_HOLD: generated controls, input box / rate limits hold by construction;
+// CAND_TABLE: controls come from the table and are checked.  BOOK = false (emit): cost and verdicts are skipped.
+// EARLY_EXIT (search): the unit stops once every candidate of the wave has failed a verdict; then only "failed" is
+// reported (vout != 0), the verdict bits are those found so far.
+template <int CAND, bool HI_ORDER, bool BOOK, bool UNIFORM, class Sink, bool EARLY_EXIT = false>
+__device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>& S, int cidx,
+                                            const double* __restrict__ table, const double* __restrict__ cinf,
+                                            Sink& sink, double& Jout, unsigned& vout, double& sN, double& vN) {
+    constexpr bool KEEP_PSI = Sink::kKeepsStates;
+    // search only needs feasible-or-not: |ey|, box v and collision are folded into one running maximum, compared with
+    // the tolerance when it is read (x > tol for some x  <=>  max x > tol; a NaN operand is ignored by both forms)
+    constexpr bool LEAN = BOOK && EARLY_EXIT;
+    typedef Fast64<HI_ORDER> FP;
+    FP fp;
+    fp.init(P, S.b0, S.b1, S.kv);
+    double x = S.x0[0], y = S.x0[1], s = S.x0[2], ey = S.x0[3], ep = S.x0[4], v = S.x0[5], psi = S.x0[6];
+    double a = S.a_prev, df = S.df_prev, da = 0.0, ddf = 0.0, J = 0.0, gmax = -1.0e300;
+    unsigned viol = 0;
+    bool dead = false;
+    const double ratio2 = fp.lr_ratio * fp.lr_ratio;
+    if (CAND == CAND_LATTICE) {
+        // da_i = -ra + (2 ra) i/(G-1), ddf_j likewise (oracle candidates_lattice)
+        const int i = cidx / P.G, j = cidx - i * P.G;
+        da = -P.rate_a + (2 * P.rate_a) * (double)i / (double)(P.G - 1);
+        ddf = -P.rate_df + (2 * P.rate_df) * (double)j / (double)(P.G - 1);
+    } else if (CAND == CAND_RAMP_HOLD) {
+        // da / ddf hold the TARGETS here (igt_device.h cand_m)
+        const int i = cidx / P.G, j = cidx - i * P.G;
+        da = clampd(S.cpar[0] + cand_m(i, P.G, P.refine_it == 0) * S.cpar[2], P.a_min, P.a_max);
+        ddf = clampd(S.cpar[1] + cand_m(j, P.G, P.refine_it == 0) * S.cpar[3], -P.df_max, P.df_max);
+    }
+    sink.state(0, 0, S.x0);
+    typename FP::Work w;
+    w.d0 = w.d1 = 0.0;
+    sincos_reduced(S.x0[6], w.s2, w.c2);       // carried as (sin,cos)(psi + beta_k); beta_{-1} = 0
+    double cb_prev = 1.0, sb_prev = 0.0;
+
+    for (int k = 0; k < P.N; ++k) {
+        // ---- controls of step k
+        if (CAND == CAND_LATTICE) {
+            a = clampd(a + da, P.a_min, P.a_max);
+            df = clampd(df + ddf, -P.df_max, P.df_max);
+        } else if (CAND == CAND_RAMP_HOLD) {
+            a = clampd(a + clampd(da - a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
+            df = clampd(df + clampd(ddf - df, -P.rate_df, P.rate_df), -P.df_max, P.df_max);
+        } else {
+            const double an = table[((size_t)cidx * 2 + 0) * P.N + k];
+            const double dn = table[((size_t)cidx * 2 + 1) * P.N + k];
+            if (BOOK) {   // input-rate (mpc.py:301-312, u_{-1} = u_prev) and input box (mpc.py:318-321)
+                if (fmax(fabs(an - a) - P.rate_a, fabs(dn - df) - P.rate_df) > P.tol) viol |= VIOL_RATE;
+                if (fmax(fmax(P.a_min - an, an - P.a_max), fmax(-P.df_max - dn, dn - P.df_max)) > P.tol) viol |= VIOL_BOX_U;
+            }
+            a = an; df = dn;
+        }
+        sink.ctrl(0, k, a, df);
+        // beta = atan(r tan df), r = l_r/(l_f+l_r):  cos(beta) = c/n, sin(beta) = r s/n, n = sqrt(c^2 + r^2 s^2)
+        double sdf, cdf;
+        if (CAND != CAND_TABLE && P.df_small) sincos_kernel(df, sdf, cdf);       // |df| <= df_max < pi/4
+        else sincos_reduced(df, sdf, cdf);
+        const double n = 1.0 / sqrt(fma(ratio2 * sdf, sdf, cdf * cdf));
+        const double cb = cdf * n, sb = fp.lr_ratio * sdf * n;
+        const double sblr = sb * fp.inv_lr;
+        // ---- bookkeeping of state k (cost in the oracle's order: control effort, epsi^2, ey^2 -- mpc.py:361-364)
+        if (BOOK) {
+            J = J + P.w_u * (a * a + df * df);
+            J = J + ep * ep;
+            J = J + ey * ey;
+            if (LEAN) {
+                gmax = fmax(gmax, fabs(ey) - P.ey_lim);                              // mpc.py:296-299
+                gmax = fmax(gmax, fmax(P.v_min - v, v - P.v_max));                   // mpc.py:316-317 (k < N)
+            } else {
+                if (fabs(ey) - P.ey_lim > P.tol) viol |= VIOL_EY;
+                if (fmax(P.v_min - v, v - P.v_max) > P.tol) viol |= VIOL_BOX_V;
+            }
+            if (k == P.N - 1) viol |= terminal_viol(P, v, a, cinf);                  // mpc.py:177-180
+        }
+        w.ey = ey; w.v1 = v;
+        if (fp.kv != 0.0) { w.d0 = s - fp.b0; w.d1 = s - fp.b1; }                    // unused on straight routes
+        // (sin,cos)(epsi): heading errors beyond pi/4 are rare, the range reduction is skipped when no lane needs it
+        if (__all(fabs(ep) < QUADRANT0)) sincos_kernel(ep, w.s1, w.c1);
+        else sincos_reduced(ep, w.s1, w.c1);
+        if (BOOK && UNIFORM && EARLY_EXIT) {
+            // search only: once every candidate of the slice has failed a verdict, nothing rolled further can win
+            const bool lost = (viol != 0) | (LEAN && gmax > P.tol);
+            if (__all(lost) && !(P.dev & 2)) { dead = true; break; }
+        }
+        if (BOOK && k >= 1) {                                                        // collision, mpc.py:223-226
+            for (int o = 0; o < P.n_obs; ++o) {
+                const double dx = x - S.obs[(o * 2 + 0) * (P.N + 1) + k], dy = y - S.obs[(o * 2 + 1) * (P.N + 1) + k];
+                const double g = P.dmin2 - (dx * dx + dy * dy);
+                if (LEAN) gmax = fmax(gmax, g);
+                else if (g > P.tol) viol |= VIOL_COLLISION;
+            }
+        }
+        rotate(w.s1, w.c1, sb, cb);                                                  // (sin,cos)(beta + epsi)
+        // (sin,cos)(psi + beta_k) from (psi + beta_{k-1}): rotate by beta_k - beta_{k-1}, re-normalise
+        {
+            const double sdb = fma(sb, cb_prev, -(cb * sb_prev));
+            const double cdb = fma(cb, cb_prev, sb * sb_prev);
+            rotate(w.s2, w.c2, sdb, cdb);
+            const double nn = fma(w.s2, w.s2, w.c2 * w.c2);
+            const double r = fma(nn, -0.5, 1.5);
+            w.s2 *= r; w.c2 *= r;
+            cb_prev = cb; sb_prev = sb;
+        }
+        w.acc_s = 0.0; w.acc_ey = 0.0; w.acc_ep = 0.0; w.acc_x = 0.0; w.acc_y = 0.0; w.acc_psi = 0.0;
+        fp.template substeps<UNIFORM>(a, sblr, w);
+        s += w.acc_s; ey += w.acc_ey; ep += w.acc_ep; x += w.acc_x; y += w.acc_y;
+        if (KEEP_PSI) psi += w.acc_psi;        // psi feeds nothing back (search: dead code)
+        v = fma(fp.dt, a, v);
+        const double nxt[7] = {x, y, s, ey, ep, v, psi};
+        sink.state(0, k + 1, nxt);
+    }
+    if (dead) {            // costs are meaningless; "failed" is what is reported
+        Jout = 0.0; vout = viol | ((LEAN && gmax > P.tol) ? VIOL_EY : 0u); sN = 0.0; vN = 0.0;
+        return;
+    }
+    if (BOOK) {
+        J = J + ep * ep;
+        J = J + ey * ey;
+        if (LEAN) gmax = fmax(gmax, fabs(ey) - P.ey_lim);
+        else if (fabs(ey) - P.ey_lim > P.tol) viol |= VIOL_EY;
+        for (int o = 0; o < P.n_obs; ++o) {
+            const double dx = x - S.obs[(o * 2 + 0) * (P.N + 1) + P.N], dy = y - S.obs[(o * 2 + 1) * (P.N + 1) + P.N];
+            const double g = P.dmin2 - (dx * dx + dy * dy);
+            if (LEAN) gmax = fmax(gmax, g);
+            else if (g > P.tol) viol |= VIOL_COLLISION;
+        }
+        if (LEAN && gmax > P.tol) viol |= VIOL_EY;     // lean form: "some state-side verdict failed"
+        if (!(fabs(x) < 1e300 && fabs(y) < 1e300 && fabs(s) < 1e300 && fabs(ey) < 1e300 && fabs(ep) < 1e300 &&
+              fabs(psi) < 1e300))
+            viol |= VIOL_NONFINITE;
+        sN = s; vN = v; Jout = J; vout = viol;
+    } else {
+        Jout = 0.0; vout = 0; sN = 0.0; vN = 0.0;
+    }
+}
+
+}  // namespace f64
+}  // namespace igt

@@ -10,6 +10,7 @@
 #define IGT_KERNELS_TU 1
 #include "igt_device.h"
 #include "igt_fast.h"
+#include "igt_fast64.h"
 #include "igt_launch.h"
 
 namespace igt {
@@ -384,8 +385,9 @@ __device__ __forceinline__ int queue_scenario(int q, int j) { return 8 * j + ((q
 // inside a class (a stable counting sort, so the order is a function of the inputs alone).
 // order[q][k] = (scenario ordinal in the queue) * 256 + slice.
 constexpr int QC = 8, QB_THREADS = 1024, QB_TRIPS = 2;     // up to 2048 units per queue (B <= 8192 at W = 2)
-__global__ __launch_bounds__(QB_THREADS) void build_queues_kernel(KP P, int B, int W, const float* __restrict__ x0,
-                                                                  const float* __restrict__ kparams,
+template <typename T>
+__global__ __launch_bounds__(QB_THREADS) void build_queues_kernel(KP P, int B, int W, const T* __restrict__ x0,
+                                                                  const T* __restrict__ kparams,
                                                                   unsigned* __restrict__ order, int stride,
                                                                   unsigned* __restrict__ work_counter) {
     __shared__ int cnt[QB_TRIPS][QB_THREADS / 64][QC];   // [trip][wave][class] counts, then exclusive offsets
@@ -401,8 +403,8 @@ __global__ __launch_bounds__(QB_THREADS) void build_queues_kernel(KP P, int B, i
             const int j = i / W, p = i - j * W, b = queue_scenario(q, j);
             c = QC - 1;                                  // a hole of the last block of 8: sorts last, skipped by the search
             if (b < B) {
-                const float s0 = x0[(size_t)b * 7 + 2], v0 = x0[(size_t)b * 7 + 5];
-                const float b0 = kparams[(size_t)b * 3 + 0], b1 = kparams[(size_t)b * 3 + 1], kv = kparams[(size_t)b * 3 + 2];
+                const float s0 = (float)x0[(size_t)b * 7 + 2], v0 = (float)x0[(size_t)b * 7 + 5];
+                const float b0 = (float)kparams[(size_t)b * 3 + 0], b1 = (float)kparams[(size_t)b * 3 + 1], kv = (float)kparams[(size_t)b * 3 + 2];
                 const float reach = s0 + 1.5f * fmaxf(v0, 1.0f) * (float)(P.N * P.dt);
                 const bool arc = kv != 0.0f && reach >= b0 && s0 <= b1;
                 const float frac = p == 0 ? 0.95f : fminf(fmaxf(1.05f - 0.15f * v0, 0.4f), 0.95f);   // share of the horizon rolled
@@ -446,15 +448,10 @@ __global__ __launch_bounds__(QB_THREADS) void build_queues_kernel(KP P, int B, i
 // small batch behind each other.  Hence one counter per XCD (workgroup n runs on XCD n mod 8), 256 B apart; queue q
 // owns one scenario of every block of 8 (queue_scenario) and deals them out scenario-major, or longest first when
 // the batch is small (build_queues_kernel); a wave whose queue is dry takes from the other queues in turn.
-template <int CAND, bool HI, bool VALUE, bool CKPT>
-__device__ __forceinline__ void search_waves(
-    const KP& P, int B, int W, int queues, unsigned* __restrict__ work_counter, const unsigned* __restrict__ order,
-    int order_stride, double* __restrict__ ckpt, int ck_parts, const float* __restrict__ x0,
-    const float* __restrict__ u_prev, const float* __restrict__ kparams, const uint32_t* __restrict__ flags,
-    const float* __restrict__ obs, const double* __restrict__ table, const double* __restrict__ cinf,
-    const double* __restrict__ cpar, double* __restrict__ part_J, int32_t* __restrict__ part_c,
-    float* __restrict__ rec_sN, float* __restrict__ rec_vN, double* __restrict__ rec_J,
-    uint32_t* __restrict__ rec_viol, unsigned* __restrict__ rec_count, int32_t* __restrict__ rec_b) {
+// `unit(b, p)` rolls slice p of scenario b (float path: search_unit, 128 candidates; double path: search_unit64, 64).
+template <class Unit>
+__device__ __forceinline__ void search_waves(const KP& P, int B, int W, int queues, unsigned* __restrict__ work_counter,
+                                             const unsigned* __restrict__ order, int order_stride, const Unit& unit) {
     const unsigned q = blockIdx.x % (unsigned)queues, uW = (unsigned)W;
     const unsigned n_scen = ((unsigned)B + 7u) / 8u;          // blocks of 8 scenarios; queue q takes one of each
     const unsigned K = n_scen * uW;
@@ -490,9 +487,7 @@ __device__ __forceinline__ void search_waves(
             const unsigned j = ord ? item >> 8 : k / uW, p = ord ? item & 255u : k - (k / uW) * uW;
             const unsigned long long t0 = (P.dev & 256) ? wall_clock64() : 0ull;
             const int b = queue_scenario((int)qq, (int)j);
-            if (b < B)
-                search_unit<CAND, HI, VALUE, CKPT>(P, W, b, (int)p, ckpt, ck_parts, B * W, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J,
-                                             part_c, rec_sN, rec_vN, rec_J, rec_viol, rec_count, rec_b);
+            if (b < B) unit(b, (int)p);
             if ((P.dev & 256) && lane0) {      // developer trace (IGT_DEV_TRACE): when each unit ran, and where
                 unsigned long long* tr =
                     reinterpret_cast<unsigned long long*>(work_counter + 1024) + ((size_t)qq * order_stride + k) * 4;
@@ -521,17 +516,24 @@ __device__ __forceinline__ void search_waves(
 #define IGT_SEARCH_PASS                                                                                              \
     P, B, W, queues, work_counter, order, order_stride, ckpt, ck_parts, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J,    \
         part_c, rec_sN, rec_vN, rec_J, rec_viol, rec_count, rec_b
+template <int CAND, bool HI, bool VALUE, bool CKPT>
+__device__ __forceinline__ void search_waves_f32(IGT_SEARCH_ARGS) {
+    search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
+        search_unit<CAND, HI, VALUE, CKPT>(P, W, b, p, ckpt, ck_parts, B * W, x0, u_prev, kparams, flags, obs, table, cinf, cpar,
+                                           part_J, part_c, rec_sN, rec_vN, rec_J, rec_viol, rec_count, rec_b);
+    });
+}
 template <int CAND, bool HI, bool VALUE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void search_fast_kernel_o3(IGT_SEARCH_ARGS) {
-    search_waves<CAND, HI, VALUE, false>(IGT_SEARCH_PASS);
+    search_waves_f32<CAND, HI, VALUE, false>(IGT_SEARCH_PASS);
 }
 template <int CAND, bool HI, bool VALUE>
 __global__ __launch_bounds__(64) void search_fast_kernel_o2(IGT_SEARCH_ARGS) {
-    search_waves<CAND, HI, VALUE, false>(IGT_SEARCH_PASS);
+    search_waves_f32<CAND, HI, VALUE, false>(IGT_SEARCH_PASS);
 }
 template <int CAND, bool HI, bool VALUE>
 __global__ __launch_bounds__(64) void search_fast_kernel_o2c(IGT_SEARCH_ARGS) {   // leaves horizon checkpoints (carries psi)
-    search_waves<CAND, HI, VALUE, true>(IGT_SEARCH_PASS);
+    search_waves_f32<CAND, HI, VALUE, true>(IGT_SEARCH_PASS);
 }
 
 template <int CAND, bool HI>
@@ -672,6 +674,161 @@ __global__ __launch_bounds__(256) void rollout_all_fast_kernel(KP P, int B, cons
             cost_all[bc] = (float)Jq;
             viol_all[bc] = viol[q];
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// float64 path (igt_fast64.h): one candidate per lane, W = C/64 units per scenario
+// ---------------------------------------------------------------------------------------
+// Generated G x G families with W * 64 == C and W | G: unit p takes G/W STEERING values (all G accelerations), handed out
+// from the centre of the range outwards, as the float path does with its 128-candidate slices -- the extreme-steering
+// units fail as a whole within a few steps and leave through the early exit.  Otherwise: chunks of 64 in index order.
+template <int CAND>
+__device__ __forceinline__ bool steering_slices64(const KP& P, int W) {
+    return CAND != CAND_TABLE && P.G * P.G == P.C && W * 64 == P.C && P.G % W == 0 && !(P.dev & 1);
+}
+template <int CAND>
+__device__ __forceinline__ int slice_candidate64(const KP& P, int W, int p, int lane) {
+    if (steering_slices64<CAND>(P, W)) {
+        const int nj = P.G / W, jl = lane % nj, il = lane / nj, r = p * nj + jl;      // il < 64 W / G = G
+        const int j = (r & 1) ? P.G / 2 - 1 - (r >> 1) : P.G / 2 + (r >> 1);
+        return il * P.G + j;
+    }
+    return p * 64 + lane;
+}
+
+#define IGT_SEARCH64_ARGS                                                                                            \
+    KP P, int B, int W, int queues, unsigned* __restrict__ work_counter, const unsigned* __restrict__ order,          \
+        int order_stride, const double* __restrict__ x0, const double* __restrict__ u_prev,                          \
+        const double* __restrict__ kparams, const uint32_t* __restrict__ flags, const double* __restrict__ obs,      \
+        const double* __restrict__ table, const double* __restrict__ cinf, const double* __restrict__ cpar,          \
+        double* __restrict__ part_J, int32_t* __restrict__ part_c, double* __restrict__ rec_sN,                      \
+        double* __restrict__ rec_vN, double* __restrict__ rec_J, uint32_t* __restrict__ rec_viol
+
+// One work unit = one (scenario, 64-candidate slice), rolled by one wave; leaves the slice's best (J, c), or -- value-net
+// cost -- every candidate's record for value_kernel<double> (mpc.py:369).
+template <int CAND, bool HI, bool VALUE>
+__device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, const double* __restrict__ x0,
+                                              const double* __restrict__ u_prev, const double* __restrict__ kparams,
+                                              const uint32_t* __restrict__ flags, const double* __restrict__ obs,
+                                              const double* __restrict__ table, const double* __restrict__ cinf,
+                                              const double* __restrict__ cpar, double* __restrict__ part_J,
+                                              int32_t* __restrict__ part_c, double* __restrict__ rec_sN,
+                                              double* __restrict__ rec_vN, double* __restrict__ rec_J,
+                                              uint32_t* __restrict__ rec_viol) {
+    const int lane = threadIdx.x & 63;
+    Scenario<double> S;
+    load_scenario<double>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
+    NullSink sink;
+    const int c = slice_candidate64<CAND>(P, W, p, lane);
+    double J, sN, vN;
+    unsigned viol;
+    f64::rollout_one<CAND, HI, true, true, NullSink, true>(P, S, c, table, cinf, sink, J, viol, sN, vN);
+    if (VALUE) {
+        const size_t idx = (size_t)b * P.C + c;
+        rec_sN[idx] = sN; rec_vN[idx] = vN; rec_J[idx] = J; rec_viol[idx] = viol;
+        return;
+    }
+    const double Jq = J - (sN - S.x0[2]);                       // mpc.py:372
+    double bestJ = Jq;
+    int bestC = ((viol == 0) && finite_d(Jq)) ? c : -1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {                   // wave butterfly arg-min, ties -> lowest candidate index
+        const double oJ = __shfl_xor(bestJ, off, 64);
+        const int oC = __shfl_xor(bestC, off, 64);
+        const bool take = (oC >= 0) && (bestC < 0 || oJ < bestJ || (oJ == bestJ && oC < bestC));
+        if (take) { bestJ = oJ; bestC = oC; }
+    }
+    if (lane == 0) { part_J[b * W + p] = bestJ; part_c[b * W + p] = bestC; }
+}
+
+// persistent waves on the per-XCD queues (search_waves), 2 or 3 per SIMD like the float kernels
+template <int CAND, bool HI, bool VALUE>
+__global__ __launch_bounds__(64) void search_f64_kernel_o2(IGT_SEARCH64_ARGS) {
+    search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
+        search_unit64<CAND, HI, VALUE>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN,
+                                       rec_vN, rec_J, rec_viol);
+    });
+}
+template <int CAND, bool HI, bool VALUE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void search_f64_kernel_o3(IGT_SEARCH64_ARGS) {
+    search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
+        search_unit64<CAND, HI, VALUE>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN,
+                                       rec_vN, rec_J, rec_viol);
+    });
+}
+
+// one lane per scenario: final arg-min over the W partials, then the winner re-rolled with the same arithmetic
+// (general sub-step variant: the lanes of the wave belong to different scenarios) -> x*[7,N+1], u*[2,N]
+template <int CAND, bool HI>
+__global__ __launch_bounds__(64) void emit_f64_kernel(KP P, int B, int W, const double* __restrict__ x0,
+                                                      const double* __restrict__ u_prev,
+                                                      const double* __restrict__ kparams,
+                                                      const uint32_t* __restrict__ flags, const double* __restrict__ obs,
+                                                      const double* __restrict__ table, const double* __restrict__ cinf,
+                                                      const double* __restrict__ cpar, const double* __restrict__ part_J,
+                                                      const int32_t* __restrict__ part_c, double* __restrict__ cost_out,
+                                                      int32_t* __restrict__ argmin_out, int32_t* __restrict__ status_out,
+                                                      double* __restrict__ x_out, double* __restrict__ u_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double bestJ = 0.0;
+    int c = -1;
+    for (int w = 0; w < W; ++w) {      // (J, c) lexicographic: ties -> lowest candidate index whatever the slice order
+        const int cw = part_c[(size_t)b * W + w];
+        const double Jw = part_J[(size_t)b * W + w];
+        if (cw >= 0 && (c < 0 || Jw < bestJ || (Jw == bestJ && cw < c))) { bestJ = Jw; c = cw; }
+    }
+    cost_out[b] = c >= 0 ? bestJ : (double)INFINITY;
+    argmin_out[b] = c;
+    status_out[b] = c >= 0 ? 0 : 1;
+    double* xo = x_out + (size_t)b * 7 * (P.N + 1);
+    double* uo = u_out + (size_t)b * 2 * P.N;
+    if (c < 0) {  // is_opt False (mpc.py:402-406): no trajectory
+        for (int i = 0; i < 7 * (P.N + 1); ++i) xo[i] = (double)NAN;
+        for (int i = 0; i < 2 * P.N; ++i) uo[i] = (double)NAN;
+        return;
+    }
+    Scenario<double> S;
+    load_scenario<double>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
+    StoreSink<double> sink{xo, uo, P.N};
+    double J, sN, vN;
+    unsigned viol;
+    f64::rollout_one<CAND, HI, false, false, StoreSink<double>>(P, S, c, table, cinf, sink, J, viol, sN, vN);
+}
+
+template <int CAND, bool HI>
+__global__ __launch_bounds__(256) void rollout_all_f64_kernel(KP P, int B, const double* __restrict__ x0,
+                                                              const double* __restrict__ u_prev,
+                                                              const double* __restrict__ kparams,
+                                                              const uint32_t* __restrict__ flags,
+                                                              const double* __restrict__ obs,
+                                                              const double* __restrict__ table,
+                                                              const double* __restrict__ cinf, const double* __restrict__ cpar,
+                                                              double* __restrict__ X_all, double* __restrict__ U_all,
+                                                              double* __restrict__ cost_all, uint32_t* __restrict__ viol_all,
+                                                              double* __restrict__ rec_sN, double* __restrict__ rec_vN,
+                                                              double* __restrict__ rec_J, uint32_t* __restrict__ rec_viol) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    Scenario<double> S;
+    load_scenario<double>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
+    for (int c = lane; c < P.C; c += 64) {          // C is a multiple of 64: the wave stays whole (votes inside)
+        const size_t bc = (size_t)b * P.C + c;
+        StoreSink<double> sink{X_all ? X_all + bc * 7 * (P.N + 1) : nullptr, U_all ? U_all + bc * 2 * P.N : nullptr, P.N};
+        double J, sN, vN;
+        unsigned viol;
+        f64::rollout_one<CAND, HI, true, true, StoreSink<double>>(P, S, c, table, cinf, sink, J, viol, sN, vN);
+        if (rec_J) {   // value-net cost: value_kernel adds the terminal term and fills cost_all / viol_all
+            rec_sN[bc] = sN; rec_vN[bc] = vN; rec_J[bc] = J; rec_viol[bc] = viol;
+            continue;
+        }
+        const double Jq = J - (sN - S.x0[2]);
+        if (!finite_d(Jq)) viol |= VIOL_NONFINITE;
+        cost_all[bc] = Jq;
+        viol_all[bc] = viol;
     }
 }
 
@@ -865,6 +1022,10 @@ bool search_builds_queues(const KP& P, int B, const SolveArgs<float>& A) {
     const int W = (P.C + 127) / 128;
     return A.queue_order && W <= 256 && ((B + 7) / 8) * W <= QB_THREADS * QB_TRIPS && !(P.dev & 16);
 }
+bool search_builds_queues(const KP& P, int B, const SolveArgs<double>& A) {
+    const int W = P.C / 64;
+    return A.queue_order && W <= 256 && ((B + 7) / 8) * W <= QB_THREADS * QB_TRIPS && !(P.dev & 16) && !(P.dev & 1024);
+}
 
 template <int CAND, bool HI, bool VALUE>
 static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>& A, hipStream_t st) {
@@ -879,7 +1040,7 @@ static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>&
     const unsigned* order = nullptr;
     const int order_stride = ((B + 7) / 8) * W;
     if (search_builds_queues(P, B, A)) {                     // small batches: longest units first
-        hipLaunchKernelGGL(build_queues_kernel, dim3(8), dim3(QB_THREADS), 0, st, P, B, W, A.x0, A.kparams, A.queue_order,
+        hipLaunchKernelGGL(build_queues_kernel<float>, dim3(8), dim3(QB_THREADS), 0, st, P, B, W, A.x0, A.kparams, A.queue_order,
                            order_stride, A.work_counter);
         order = A.queue_order;
     }
@@ -913,9 +1074,48 @@ template <>
 hipError_t launch_search<float>(const KP& P, int B, const SolveArgs<float>& A, int, hipStream_t st) {
     return dispatch_search_fast<false>(P, B, A, st);
 }
+// float64 search: persistent waves on the per-XCD queues, one 64-candidate unit at a time
+template <int CAND, bool HI, bool VALUE>
+static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A, hipStream_t st) {
+    const int W = P.C / 64;
+    const size_t total = (size_t)B * W;
+    // 3 waves per SIMD from 16 units per wave slot upwards, else 2 (same rule as the float kernels)
+    const bool big = total >= (size_t)A.n_cu * 12 * 16;
+    const bool o3 = (P.dev & 8) ? false : (P.dev & 32) ? true : big;
+    const size_t slots = (size_t)A.n_cu * 4 * (o3 ? 3 : 2);
+    const size_t grid = total < slots ? total : slots;
+    const unsigned* order = nullptr;
+    const int order_stride = ((B + 7) / 8) * W;
+    if (search_builds_queues(P, B, A)) {                     // small batches: longest units first
+        hipLaunchKernelGGL(build_queues_kernel<double>, dim3(8), dim3(QB_THREADS), 0, st, P, B, W, A.x0, A.kparams,
+                           A.queue_order, order_stride, A.work_counter);
+        order = A.queue_order;
+    }
+    if (o3)
+        hipLaunchKernelGGL((search_f64_kernel_o3<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter, order,
+                           order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c,
+                           A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
+    else
+        hipLaunchKernelGGL((search_f64_kernel_o2<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter, order,
+                           order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c,
+                           A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
+    return hipGetLastError();
+}
+template <bool VALUE>
+static hipError_t dispatch_search64(const KP& P, int B, const SolveArgs<double>& A, hipStream_t st) {
+    if (P.dev & 1024) return launch_search_exact<VALUE>(P, B, A, st);     // developer switch: oracle-order kernels
+    if (P.hi_order) {
+        if (P.cand_mode == CAND_LATTICE) return launch_search64<CAND_LATTICE, true, VALUE>(P, B, A, st);
+        if (P.cand_mode == CAND_RAMP_HOLD) return launch_search64<CAND_RAMP_HOLD, true, VALUE>(P, B, A, st);
+        return launch_search64<CAND_TABLE, true, VALUE>(P, B, A, st);
+    }
+    if (P.cand_mode == CAND_LATTICE) return launch_search64<CAND_LATTICE, false, VALUE>(P, B, A, st);
+    if (P.cand_mode == CAND_RAMP_HOLD) return launch_search64<CAND_RAMP_HOLD, false, VALUE>(P, B, A, st);
+    return launch_search64<CAND_TABLE, false, VALUE>(P, B, A, st);
+}
 template <>
 hipError_t launch_search<double>(const KP& P, int B, const SolveArgs<double>& A, int, hipStream_t st) {
-    return launch_search_exact<false>(P, B, A, st);
+    return dispatch_search64<false>(P, B, A, st);
 }
 template <>
 hipError_t launch_search_records<float>(const KP& P, int B, const SolveArgs<float>& A, hipStream_t st) {
@@ -923,7 +1123,7 @@ hipError_t launch_search_records<float>(const KP& P, int B, const SolveArgs<floa
 }
 template <>
 hipError_t launch_search_records<double>(const KP& P, int B, const SolveArgs<double>& A, hipStream_t st) {
-    return launch_search_exact<true>(P, B, A, st);
+    return dispatch_search64<true>(P, B, A, st);
 }
 
 // dynamic-LDS limits of the value kernels, raised once when a net is loaded (igt_set_value_net) -- not on the launch
@@ -1038,11 +1238,28 @@ hipError_t launch_emit<float>(const KP& P, int B, int W, const SolveArgs<float>&
     if (P.cand_mode == CAND_RAMP_HOLD) return launch_emit_fast<CAND_RAMP_HOLD, false>(P, B, W, A, st);
     return launch_emit_fast<CAND_TABLE, false>(P, B, W, A, st);
 }
-template <>
-hipError_t launch_emit<double>(const KP& P, int B, int, const SolveArgs<double>& A, hipStream_t st) {
-    hipLaunchKernelGGL((emit_kernel<ExactStepper<double>, double>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, A.x0,
-                       A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.argmin_out, A.x_out, A.u_out);
+template <int CAND, bool HI>
+static hipError_t launch_emit64(const KP& P, int B, int W, const SolveArgs<double>& A, hipStream_t st) {
+    hipLaunchKernelGGL((emit_f64_kernel<CAND, HI>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, W, A.x0, A.u_prev, A.kparams,
+                       A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.cost_out, A.argmin_out, A.status_out,
+                       A.x_out, A.u_out);
     return hipGetLastError();
+}
+template <>
+hipError_t launch_emit<double>(const KP& P, int B, int W, const SolveArgs<double>& A, hipStream_t st) {
+    if (P.dev & 1024) {     // developer switch: oracle-order kernels (argmin_out is already final there)
+        hipLaunchKernelGGL((emit_kernel<ExactStepper<double>, double>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, A.x0,
+                           A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.argmin_out, A.x_out, A.u_out);
+        return hipGetLastError();
+    }
+    if (P.hi_order) {
+        if (P.cand_mode == CAND_LATTICE) return launch_emit64<CAND_LATTICE, true>(P, B, W, A, st);
+        if (P.cand_mode == CAND_RAMP_HOLD) return launch_emit64<CAND_RAMP_HOLD, true>(P, B, W, A, st);
+        return launch_emit64<CAND_TABLE, true>(P, B, W, A, st);
+    }
+    if (P.cand_mode == CAND_LATTICE) return launch_emit64<CAND_LATTICE, false>(P, B, W, A, st);
+    if (P.cand_mode == CAND_RAMP_HOLD) return launch_emit64<CAND_RAMP_HOLD, false>(P, B, W, A, st);
+    return launch_emit64<CAND_TABLE, false>(P, B, W, A, st);
 }
 
 template <int CAND, bool HI>
@@ -1065,13 +1282,31 @@ hipError_t launch_rollout_all<float>(const KP& P, int B, const SolveArgs<float>&
     if (P.cand_mode == CAND_RAMP_HOLD) return launch_rollout_all_fast<CAND_RAMP_HOLD, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
     return launch_rollout_all_fast<CAND_TABLE, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
 }
+template <int CAND, bool HI>
+static hipError_t launch_rollout_all64(const KP& P, int B, const SolveArgs<double>& A, double* X_all, double* U_all,
+                                       double* cost_all, uint32_t* viol_all, hipStream_t st) {
+    hipLaunchKernelGGL((rollout_all_f64_kernel<CAND, HI>), dim3((B + 3) / 4), dim3(256), 0, st, P, B, A.x0, A.u_prev,
+                       A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, X_all, U_all, cost_all, viol_all, A.rec_sN, A.rec_vN,
+                       A.rec_J, A.rec_viol);
+    return hipGetLastError();
+}
 template <>
 hipError_t launch_rollout_all<double>(const KP& P, int B, const SolveArgs<double>& A, double* X_all, double* U_all,
                                       double* cost_all, uint32_t* viol_all, hipStream_t st) {
-    hipLaunchKernelGGL((rollout_all_kernel<ExactStepper<double>, double>), dim3((B + 3) / 4), dim3(256), 0, st, P, B,
-                       A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, X_all, U_all, cost_all, viol_all,
-                       A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
-    return hipGetLastError();
+    if (P.dev & 1024) {     // developer switch: oracle-order kernels
+        hipLaunchKernelGGL((rollout_all_kernel<ExactStepper<double>, double>), dim3((B + 3) / 4), dim3(256), 0, st, P, B,
+                           A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, X_all, U_all, cost_all, viol_all,
+                           A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
+        return hipGetLastError();
+    }
+    if (P.hi_order) {
+        if (P.cand_mode == CAND_LATTICE) return launch_rollout_all64<CAND_LATTICE, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+        if (P.cand_mode == CAND_RAMP_HOLD) return launch_rollout_all64<CAND_RAMP_HOLD, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+        return launch_rollout_all64<CAND_TABLE, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+    }
+    if (P.cand_mode == CAND_LATTICE) return launch_rollout_all64<CAND_LATTICE, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+    if (P.cand_mode == CAND_RAMP_HOLD) return launch_rollout_all64<CAND_RAMP_HOLD, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+    return launch_rollout_all64<CAND_TABLE, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
 }
 
 template <>

@@ -44,6 +44,7 @@ struct SolveArgs {   // all device pointers
 };
 
 bool search_builds_queues(const KP& P, int B, const SolveArgs<float>& A);   // then no memset of the counters is needed
+bool search_builds_queues(const KP& P, int B, const SolveArgs<double>& A);
 template <typename T> hipError_t launch_search(const KP& P, int B, const SolveArgs<T>& A, int nc, hipStream_t st);
 template <typename T> hipError_t launch_emit(const KP& P, int B, int W, const SolveArgs<T>& A, hipStream_t st);
 // value-net cost: search pass that writes per-candidate records, then prep + MLP + per-chunk arg-min

@@ -116,13 +116,15 @@ def test_solve_matches_oracle(igt, dtype, tol, eps):
         assert np.isinf(got['cost'][bad]).all() and (got['argmin'][bad] == -1).all()
 
 
-@pytest.mark.parametrize('B,cand_mode', [(64, 'lattice'), (64, 'ramp_hold'), (2304, 'lattice')])
-def test_search_and_emit_agree_bitwise(igt, B, cand_mode):
+@pytest.mark.parametrize('B,cand_mode,dtype', [(64, 'lattice', 'f32'), (64, 'ramp_hold', 'f32'), (2304, 'lattice', 'f32'),
+                                               (64, 'lattice', 'f64'), (64, 'ramp_hold', 'f64'), (2304, 'lattice', 'f64')])
+def test_search_and_emit_agree_bitwise(igt, B, cand_mode, dtype):
     """emit re-rolls the winner with the arithmetic search used: the trajectory it stores must be exactly the
-    rollout_all trajectory of that candidate.  Up to B = 2048 emit resumes four quarters of the horizon from the
-    search pass's checkpoints (one lane each); above, it rolls the horizon in one piece: both must hold."""
-    b = _batch(B, np.float32)
-    with igt.BatchSolver(dtype='f32', cand_mode=cand_mode) as s:
+    rollout_all trajectory of that candidate.  f32: up to B = 2048 emit resumes four quarters of the horizon from the
+    search pass's checkpoints (one lane each); above, it rolls the horizon in one piece: both must hold.  f64: search
+    picks its sub-step variant by wave votes, emit uses the general one, rollout-all votes with other lane make-ups."""
+    b = _batch(B, np.float32 if dtype == 'f32' else np.float64)
+    with igt.BatchSolver(dtype=dtype, cand_mode=cand_mode) as s:
         s.set_cinf(*_cinf())
         sol = s.solve(*_args(b))
         n = min(B, 96)
@@ -135,6 +137,40 @@ def test_search_and_emit_agree_bitwise(igt, B, cand_mode):
             assert np.array_equal(sol['u'][i], allc['U'][i, c])
             assert sol['cost'][i] == allc['cost'][i, c]
             assert allc['viol'][i, c] == 0
+
+
+def test_f64_production_kernels_agree_with_oracle_order_kernels(igt, monkeypatch):
+    """The float64 entry runs the factorised double arithmetic of igt_fast64.h on persistent waves; the kernels that
+    follow the oracle operation for operation (ExactStepper<double>) stay in the library behind IGT_DEV_FLAGS=1024.
+    At BASELINE configs[1] size, where the numpy oracle is too slow to cover every scenario, the two must agree:
+    same status everywhere, same arg-min except exact near-ties, trajectories and costs to 1e-11."""
+    B = 4096
+    b = _batch(B, np.float64)
+    with igt.BatchSolver(dtype='f64') as s:
+        s.set_cinf(*_cinf())
+        fast = s.solve(*_args(b))
+        allf = s.rollout_all(*[a[:64] for a in _args(b)])
+    monkeypatch.setenv('IGT_DEV_FLAGS', '1024')
+    with igt.BatchSolver(dtype='f64') as s:
+        s.set_cinf(*_cinf())
+        ref = s.solve(*_args(b))
+        allr = s.rollout_all(*[a[:64] for a in _args(b)])
+    assert np.array_equal(fast['status'], ref['status'])
+    same = fast['argmin'] == ref['argmin']
+    assert same.mean() > 0.999
+    ok = same & (ref['status'] == 0)
+    assert rel_err(fast['x'][ok], ref['x'][ok]).max() < 1e-11
+    assert rel_err(fast['cost'][ok], ref['cost'][ok]).max() < 1e-11
+    assert np.array_equal(fast['u'][ok], ref['u'][ok])
+    # a different winner is only acceptable as a near-tie of the cost
+    diff = ~same
+    assert rel_err(fast['cost'][diff], ref['cost'][diff]).max(initial=0.0) < 1e-11
+    # every candidate of 64 scenarios (infeasible ones included)
+    assert rel_err(allf['X'], allr['X']).max() < 1e-11
+    assert np.array_equal(allf['U'], allr['U'])
+    fin = np.isfinite(allr['cost'])
+    assert rel_err(allf['cost'][fin], allr['cost'][fin]).max() < 1e-11
+    assert (allf['viol'] == allr['viol']).mean() > 0.9995
 
 
 # ----------------------------------------------------------------------------- golden vectors
