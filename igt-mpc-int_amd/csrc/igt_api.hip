@@ -160,8 +160,8 @@ inline bool counters_by_builder(const igt::KP& kp, int B, const igt::SolveArgs<T
 
 template <typename T>
 int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* kparams, const uint32_t* flags,
-               const T* obs_xy, const T* tv_sv, const T* enc, T* x_out, T* u_out, T* cost_out, int32_t* argmin_out,
-               int32_t* status_out, int mem, void* stream) {
+               const T* obs_xy, const T* tv_sv, const T* enc, const T* u_ws, T* x_out, T* u_out, T* cost_out,
+               int32_t* argmin_out, int32_t* status_out, int mem, void* stream) {
     if (!h) return fail(IGT_E_INVALID, "null handle");
     if (B < 0) return fail(IGT_E_INVALID, "B < 0");
     if (B == 0) return IGT_OK;
@@ -170,6 +170,8 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     const igt_params& p = h->p;
     if (p.n_obs > 0 && !obs_xy) return fail(IGT_E_INVALID, "obs_xy is null but n_obs > 0");
     if (p.cand_mode == IGT_CAND_TABLE && !h->table_set) return fail(IGT_E_STATE, "candidate table not set");
+    if (u_ws && p.cand_mode != IGT_CAND_RAMP_HOLD)
+        return fail(IGT_E_INVALID, "a warm start needs IGT_CAND_RAMP_HOLD (the family whose targets are centred on it)");
     const bool value = p.cost_mode == IGT_COST_VALUE_NET;
     if (value) {
         if (!h->net_set) return fail(IGT_E_STATE, "value net not set (igt_set_value_net)");
@@ -186,10 +188,10 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     A.cinf = h->kp.F > 0 ? h->d_cinf : nullptr;
     if (mem == IGT_MEM_DEVICE) {
         A.x0 = x0; A.u_prev = u_prev; A.kparams = kparams; A.flags = flags; A.obs = obs_xy;
-        A.tv_sv = tv_sv; A.enc = enc;
+        A.tv_sv = tv_sv; A.enc = enc; A.u_ws = u_ws;
         A.x_out = x_out; A.u_out = u_out; A.cost_out = cost_out; A.argmin_out = argmin_out; A.status_out = status_out;
     } else if (mem == IGT_MEM_HOST) {
-        const size_t bytes = (n_x + 3 * n_u + n_k + n_obs + n_xo + n_uo + B) * sizeof(T) + (size_t)B * 12 + 20 * 256;
+        const size_t bytes = (n_x + 3 * n_u + n_k + n_obs + n_xo + 2 * n_uo + B) * sizeof(T) + (size_t)B * 12 + 24 * 256;
         if (int rc = ensure_stage(h, bytes)) return rc;
         Arena ar{(char*)h->d_stage, 0};
         T* dx0 = ar.take<T>(n_x); T* dup = ar.take<T>(n_u); T* dk = ar.take<T>(n_k);
@@ -202,6 +204,11 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
             HIPCHK(hipMemcpyAsync(den, enc, n_u * sizeof(T), hipMemcpyHostToDevice, st));
         }
         A.tv_sv = dtv; A.enc = den;
+        if (u_ws) {
+            T* dws = ar.take<T>(n_uo);
+            HIPCHK(hipMemcpyAsync(dws, u_ws, n_uo * sizeof(T), hipMemcpyHostToDevice, st));
+            A.u_ws = dws;
+        }
         HIPCHK(hipMemcpyAsync(dx0, x0, n_x * sizeof(T), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(dup, u_prev, n_u * sizeof(T), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(dk, kparams, n_k * sizeof(T), hipMemcpyHostToDevice, st));
@@ -233,7 +240,7 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     }
     const bool use_ckpt = ck_parts > 1;
     const size_t ckpt_bytes = use_ckpt ? (size_t)(ck_parts - 1) * B * Wk * igt::SEG_UNIT_DOUBLES * 8 + 256 : 0;
-    double *d_cpar = nullptr, *d_uprev = nullptr;
+    double* d_cpar = nullptr;
     {
         const size_t n_rec = value ? (size_t)B * p.C : 0;
         const size_t need = (size_t)B * W * 12 + (size_t)B * 56 + 8192 + ckpt_bytes + (size_t)(B + 8) * Wk * 36 + 256 + n_rec * (2 * sizeof(T) + 16) +
@@ -243,7 +250,6 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
         A.part_J = wa.take<double>((size_t)B * W);
         A.part_c = wa.take<int32_t>((size_t)B * W);
         d_cpar = wa.take<double>((size_t)B * 4);
-        d_uprev = wa.take<double>((size_t)B * 2);
         const bool trace = (h->kp.dev & 256) != 0;      // developer trace: 32 B per unit behind the counters
         A.work_counter = wa.take<unsigned>(1024 + (trace ? (size_t)((B + 7) / 8) * 8 * Wk * 8 : 0));
         A.n_cu = h->n_cu;
@@ -291,7 +297,7 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
                 R.part_c = A.argmin_out;
                 Wr = 1;
             }
-            HIPCHK(igt::launch_refine<T>(kp, B, Wr, R, d_uprev, d_cpar, it == 0 ? 1 : 0, st));
+            HIPCHK(igt::launch_refine<T>(kp, B, Wr, R, d_cpar, it == 0 ? 1 : 0, st));
         }
     }
     if (h->prof) HIPCHK(hipEventRecord(h->ev[1], st));
@@ -320,8 +326,8 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
 
 template <typename T>
 int rollout_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* kparams, const uint32_t* flags,
-                 const T* obs_xy, const T* tv_sv, const T* enc, T* X_all, T* U_all, T* cost_all, uint32_t* viol_all,
-                 int mem, void* stream) {
+                 const T* obs_xy, const T* tv_sv, const T* enc, const T* u_ws, T* X_all, T* U_all, T* cost_all,
+                 uint32_t* viol_all, int mem, void* stream) {
     if (!h) return fail(IGT_E_INVALID, "null handle");
     if (B < 0) return fail(IGT_E_INVALID, "B < 0");
     if (B == 0) return IGT_OK;
@@ -329,6 +335,8 @@ int rollout_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T
     const igt_params& p = h->p;
     if (p.n_obs > 0 && !obs_xy) return fail(IGT_E_INVALID, "obs_xy is null but n_obs > 0");
     if (p.cand_mode == IGT_CAND_TABLE && !h->table_set) return fail(IGT_E_STATE, "candidate table not set");
+    if (u_ws && p.cand_mode != IGT_CAND_RAMP_HOLD)
+        return fail(IGT_E_INVALID, "a warm start needs IGT_CAND_RAMP_HOLD (the family whose targets are centred on it)");
     const bool value = p.cost_mode == IGT_COST_VALUE_NET;
     if (value) {
         if (!h->net_set) return fail(IGT_E_STATE, "value net not set (igt_set_value_net)");
@@ -346,10 +354,11 @@ int rollout_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T
     uint32_t* dv = viol_all;
     if (mem == IGT_MEM_DEVICE) {
         A.x0 = x0; A.u_prev = u_prev; A.kparams = kparams; A.flags = flags; A.obs = obs_xy;
-        A.tv_sv = tv_sv; A.enc = enc;
+        A.tv_sv = tv_sv; A.enc = enc; A.u_ws = u_ws;
     } else if (mem == IGT_MEM_HOST) {
-        const size_t bytes = (n_x + 3 * n_u + n_k + n_obs + (X_all ? n_X : 0) + (U_all ? n_U : 0) + n_c) * sizeof(T) +
-                             n_c * 4 + (size_t)B * 4 + 20 * 256;
+        const size_t n_ws = u_ws ? (size_t)B * 2 * p.N : 0;
+        const size_t bytes = (n_x + 3 * n_u + n_k + n_obs + (X_all ? n_X : 0) + (U_all ? n_U : 0) + n_c + n_ws) * sizeof(T) +
+                             n_c * 4 + (size_t)B * 4 + 24 * 256;
         if (int rc = ensure_stage(h, bytes)) return rc;
         Arena ar{(char*)h->d_stage, 0};
         T* dx0 = ar.take<T>(n_x); T* dup = ar.take<T>(n_u); T* dk = ar.take<T>(n_k);
@@ -363,6 +372,11 @@ int rollout_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T
             HIPCHK(hipMemcpyAsync(den, enc, n_u * sizeof(T), hipMemcpyHostToDevice, st));
         }
         A.tv_sv = dtv; A.enc = den;
+        if (u_ws) {
+            T* dws = ar.take<T>(n_ws);
+            HIPCHK(hipMemcpyAsync(dws, u_ws, n_ws * sizeof(T), hipMemcpyHostToDevice, st));
+            A.u_ws = dws;
+        }
         HIPCHK(hipMemcpyAsync(dx0, x0, n_x * sizeof(T), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(dup, u_prev, n_u * sizeof(T), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(dk, kparams, n_k * sizeof(T), hipMemcpyHostToDevice, st));
@@ -725,28 +739,56 @@ int igt_set_value_net(igt_handle* h, int32_t n_layers, const int32_t* dims, cons
 int igt_solve_batch_f32(igt_handle* h, int32_t B, const float* x0, const float* u_prev, const float* kparams,
                         const uint32_t* flags, const float* obs_xy, const float* tv_sv, const float* enc, float* x_out,
                         float* u_out, float* cost_out, int32_t* argmin_out, int32_t* status_out, int mem, void* stream) {
-    return solve_impl<float>(h, B, x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, x_out, u_out, cost_out, argmin_out,
-                             status_out, mem, stream);
+    return solve_impl<float>(h, B, x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, nullptr, x_out, u_out, cost_out,
+                             argmin_out, status_out, mem, stream);
 }
 int igt_solve_batch_f64(igt_handle* h, int32_t B, const double* x0, const double* u_prev, const double* kparams,
                         const uint32_t* flags, const double* obs_xy, const double* tv_sv, const double* enc,
                         double* x_out, double* u_out, double* cost_out, int32_t* argmin_out, int32_t* status_out,
                         int mem, void* stream) {
-    return solve_impl<double>(h, B, x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, x_out, u_out, cost_out,
+    return solve_impl<double>(h, B, x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, nullptr, x_out, u_out, cost_out,
+                              argmin_out, status_out, mem, stream);
+}
+int igt_solve_batch_ws_f32(igt_handle* h, int32_t B, const float* x0, const float* u_prev, const float* kparams,
+                           const uint32_t* flags, const float* obs_xy, const float* tv_sv, const float* enc,
+                           const float* u_ws, float* x_out, float* u_out, float* cost_out, int32_t* argmin_out,
+                           int32_t* status_out, int mem, void* stream) {
+    return solve_impl<float>(h, B, x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, u_ws, x_out, u_out, cost_out,
+                             argmin_out, status_out, mem, stream);
+}
+int igt_solve_batch_ws_f64(igt_handle* h, int32_t B, const double* x0, const double* u_prev, const double* kparams,
+                           const uint32_t* flags, const double* obs_xy, const double* tv_sv, const double* enc,
+                           const double* u_ws, double* x_out, double* u_out, double* cost_out, int32_t* argmin_out,
+                           int32_t* status_out, int mem, void* stream) {
+    return solve_impl<double>(h, B, x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, u_ws, x_out, u_out, cost_out,
                               argmin_out, status_out, mem, stream);
 }
 
 int igt_rollout_batch_f32(igt_handle* h, int32_t B, const float* x0, const float* u_prev, const float* kparams,
                           const uint32_t* flags, const float* obs_xy, const float* tv_sv, const float* enc,
                           float* X_all, float* U_all, float* cost_all, uint32_t* viol_all, int mem, void* stream) {
-    return rollout_impl<float>(h, B, x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, X_all, U_all, cost_all, viol_all, mem,
-                               stream);
+    return rollout_impl<float>(h, B, x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, nullptr, X_all, U_all, cost_all,
+                               viol_all, mem, stream);
 }
 int igt_rollout_batch_f64(igt_handle* h, int32_t B, const double* x0, const double* u_prev, const double* kparams,
                           const uint32_t* flags, const double* obs_xy, const double* tv_sv, const double* enc,
                           double* X_all, double* U_all, double* cost_all, uint32_t* viol_all, int mem, void* stream) {
-    return rollout_impl<double>(h, B, x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, X_all, U_all, cost_all, viol_all, mem,
-                                stream);
+    return rollout_impl<double>(h, B, x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, nullptr, X_all, U_all, cost_all,
+                                viol_all, mem, stream);
+}
+int igt_rollout_batch_ws_f32(igt_handle* h, int32_t B, const float* x0, const float* u_prev, const float* kparams,
+                             const uint32_t* flags, const float* obs_xy, const float* tv_sv, const float* enc,
+                             const float* u_ws, float* X_all, float* U_all, float* cost_all, uint32_t* viol_all, int mem,
+                             void* stream) {
+    return rollout_impl<float>(h, B, x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, u_ws, X_all, U_all, cost_all,
+                               viol_all, mem, stream);
+}
+int igt_rollout_batch_ws_f64(igt_handle* h, int32_t B, const double* x0, const double* u_prev, const double* kparams,
+                             const uint32_t* flags, const double* obs_xy, const double* tv_sv, const double* enc,
+                             const double* u_ws, double* X_all, double* U_all, double* cost_all, uint32_t* viol_all,
+                             int mem, void* stream) {
+    return rollout_impl<double>(h, B, x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, u_ws, X_all, U_all, cost_all,
+                                viol_all, mem, stream);
 }
 
 int igt_frenet_step_f32(igt_handle* h, int32_t n, const float* x, const float* u, const float* kparams, float* x_next,

@@ -42,13 +42,22 @@ __device__ __forceinline__ double clampd(double x, double lo, double hi) {
 
 struct Ctl {
     double a, df;        // last generated control
-    double da, ddf;      // lattice increments  /  ramp-hold: targets (a_tgt, df_tgt)
+    double da, ddf;      // lattice increments  /  ramp-hold: offsets of the targets from the base sequence
 };
+// base sequence of the ramp-hold targets at step k
+template <typename T>
+__device__ __forceinline__ void ramp_base(const T* __restrict__ ws, int N, int k, double a_prev, double df_prev, double& ba,
+                                          double& bdf) {
+    ba = ws ? (double)ws[k] : a_prev;
+    bdf = ws ? (double)ws[N + k] : df_prev;
+}
 
-// Ramp-and-hold family (IGT_CAND_RAMP_HOLD): candidate (i, j) ramps a and df at the rate limits towards
-//   a_tgt = clamp(center_a + m(u_i) span_a),  df_tgt = clamp(center_df + m(u_j) span_df),  u_i = (i - G/2)/(G/2)
-// and holds them.  First pass: m(u) = u |u| sqrt|u| (dense around the centre = u_prev, span = N * rate limit);
-// refinement passes: m(u) = u around the previous winner's targets (refine_targets_kernel).
+// Ramp-and-hold family (IGT_CAND_RAMP_HOLD): candidate (i, j) tracks, at the rate limits (mpc.py:301-312),
+//   a_tgt,k = clamp(base_a,k + off_a),  off_a = c_a + m(u_i) span_a,   u_i = (i - G/2)/(G/2)      (df likewise with j)
+// where the base sequence is u_prev held over the horizon or -- warm start -- the previous solution shifted by one
+// step (utils.py:354-363).  First pass: c = 0, m(u) = u |u| sqrt|u| (dense around the base; span = N * rate limit);
+// refinement passes: m(u) = u around the previous winner's offset (refine_targets_kernel).  The candidate with
+// offset 0 (i = j = G/2) IS the base sequence wherever that respects the limits.
 __device__ __forceinline__ double cand_m(int i, int G, bool first) {
     const double u = (double)(i - G / 2) / (double)(G / 2);
     return first ? u * fabs(u) * sqrt(fabs(u)) : u;
@@ -60,9 +69,9 @@ __device__ __forceinline__ void ctl_init(Ctl& c, const KP& P, int idx, double a_
     c.a = a_prev;
     c.df = df_prev;
     const int i = idx / P.G, j = idx - i * P.G;
-    if (P.cand_mode == CAND_RAMP_HOLD) {
-        c.da = clampd(cpar[0] + cand_m(i, P.G, P.refine_it == 0) * cpar[2], P.a_min, P.a_max);
-        c.ddf = clampd(cpar[1] + cand_m(j, P.G, P.refine_it == 0) * cpar[3], -P.df_max, P.df_max);
+    if (P.cand_mode == CAND_RAMP_HOLD) {     // da / ddf hold the OFFSETS from the base sequence
+        c.da = cpar[0] + cand_m(i, P.G, P.refine_it == 0) * cpar[2];
+        c.ddf = cpar[1] + cand_m(j, P.G, P.refine_it == 0) * cpar[3];
         return;
     }
     // da_i = -ra + (2 ra) i / (G-1)   (oracle candidates_lattice)
@@ -71,8 +80,9 @@ __device__ __forceinline__ void ctl_init(Ctl& c, const KP& P, int idx, double a_
 }
 
 // advances to step k; returns violation bits for the input box / rate constraints
-__device__ __forceinline__ unsigned ctl_step(Ctl& c, const KP& P, int idx, int k,
-                                             const double* __restrict__ table) {
+template <typename T>
+__device__ __forceinline__ unsigned ctl_step(Ctl& c, const KP& P, int idx, int k, const double* __restrict__ table,
+                                             const T* __restrict__ ws, double a_prev, double df_prev) {
     unsigned v = 0;
     if (P.cand_mode == CAND_TABLE) {
         const double a = table[((size_t)idx * 2 + 0) * P.N + k];
@@ -82,8 +92,11 @@ __device__ __forceinline__ unsigned ctl_step(Ctl& c, const KP& P, int idx, int k
         c.a = a;
         c.df = d;
     } else if (P.cand_mode == CAND_RAMP_HOLD) {
-        c.a = clampd(c.a + clampd(c.da - c.a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
-        c.df = clampd(c.df + clampd(c.ddf - c.df, -P.rate_df, P.rate_df), -P.df_max, P.df_max);
+        double ba, bdf;
+        ramp_base<T>(ws, P.N, k, a_prev, df_prev, ba, bdf);
+        const double ta = clampd(ba + c.da, P.a_min, P.a_max), tdf = clampd(bdf + c.ddf, -P.df_max, P.df_max);
+        c.a = clampd(c.a + clampd(ta - c.a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
+        c.df = clampd(c.df + clampd(tdf - c.df, -P.rate_df, P.rate_df), -P.df_max, P.df_max);
     } else {
         c.a = clampd(c.a + c.da, P.a_min, P.a_max);
         c.df = clampd(c.df + c.ddf, -P.df_max, P.df_max);
@@ -255,8 +268,17 @@ struct Scenario {           // wave-uniform inputs of one scenario
     double x0[7];
     double a_prev, df_prev;
     double b0, b1, kv;
-    double cpar[4];         // ramp-hold candidates: centre (a, df) and span (a, df)
+    double cpar[4];         // ramp-hold candidates: centre offset (a, df) and span (a, df)
     const T* obs;           // [n_obs, 2, N+1]
+    const T* ws;            // [2, N] warm start of this scenario (base sequence of the ramp-hold targets), or null
+};
+
+// what the candidate generators are centred on: refinement parameters [B,4] (null: first pass) and the batch's warm
+// starts [B,2,N] (null: none)
+template <typename T>
+struct Centre {
+    const double* cpar;
+    const T* ws;
 };
 
 // Horizon checkpoints (small batches).  The search pass leaves every still-feasible candidate's state at `parts - 1`
@@ -309,7 +331,7 @@ __device__ __forceinline__ void rollout_pass(const KP& P, const Scenario<T>& S, 
         typename Stepper::Beta B[NC];
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
-            bk[q].viol |= ctl_step(ctl[q], P, cidx[q], k, table);
+            bk[q].viol |= ctl_step<T>(ctl[q], P, cidx[q], k, table, S.ws, S.a_prev, S.df_prev);
             sink.ctrl(q, k, ctl[q].a, ctl[q].df);
             // control effort first, then the tracking terms of state k (mpc.py:361-364)
             bk[q].J = bk[q].J + P.w_u * (ctl[q].a * ctl[q].a + ctl[q].df * ctl[q].df);

@@ -288,10 +288,10 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
         da = -P.rate_a + (2 * P.rate_a) * (double)i / (double)(P.G - 1);
         ddf = -P.rate_df + (2 * P.rate_df) * (double)j / (double)(P.G - 1);
     } else if (CAND == CAND_RAMP_HOLD) {
-        // da / ddf hold the TARGETS here (igt_device.h cand_m)
+        // da / ddf hold the OFFSETS of the targets from the base sequence here (igt_device.h cand_m, ramp_base)
         const int i = cidx / P.G, j = cidx - i * P.G;
-        da = clampd(S.cpar[0] + cand_m(i, P.G, P.refine_it == 0) * S.cpar[2], P.a_min, P.a_max);
-        ddf = clampd(S.cpar[1] + cand_m(j, P.G, P.refine_it == 0) * S.cpar[3], -P.df_max, P.df_max);
+        da = S.cpar[0] + cand_m(i, P.G, P.refine_it == 0) * S.cpar[2];
+        ddf = S.cpar[1] + cand_m(j, P.G, P.refine_it == 0) * S.cpar[3];
     }
     sink.state(0, 0, S.x0);
     typename FP::Work w;
@@ -305,8 +305,11 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
             a = clampd(a + da, P.a_min, P.a_max);
             df = clampd(df + ddf, -P.df_max, P.df_max);
         } else if (CAND == CAND_RAMP_HOLD) {
-            a = clampd(a + clampd(da - a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
-            df = clampd(df + clampd(ddf - df, -P.rate_df, P.rate_df), -P.df_max, P.df_max);
+            double ba, bdf;
+            ramp_base<double>(S.ws, P.N, k, S.a_prev, S.df_prev, ba, bdf);
+            const double ta = clampd(ba + da, P.a_min, P.a_max), tdf = clampd(bdf + ddf, -P.df_max, P.df_max);
+            a = clampd(a + clampd(ta - a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
+            df = clampd(df + clampd(tdf - df, -P.rate_df, P.rate_df), -P.df_max, P.df_max);
         } else {
             const double an = table[((size_t)cidx * 2 + 0) * P.N + k];
             const double dn = table[((size_t)cidx * 2 + 1) * P.N + k];

@@ -19,7 +19,7 @@ template <typename T>
 __device__ __forceinline__ void load_scenario(Scenario<T>& S, const KP& P, int b, const T* __restrict__ x0,
                                               const T* __restrict__ u_prev, const T* __restrict__ kparams,
                                               const uint32_t* __restrict__ flags, const T* __restrict__ obs,
-                                              const double* __restrict__ cpar = nullptr) {
+                                              Centre<T> cpar = Centre<T>{nullptr, nullptr}) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) S.x0[i] = (double)x0[(size_t)b * 7 + i];
     // ego routes '32','41' use |heading| (mpc.py:231-234, 282-285)
@@ -30,11 +30,14 @@ __device__ __forceinline__ void load_scenario(Scenario<T>& S, const KP& P, int b
     S.b1 = (double)kparams[(size_t)b * 3 + 1];
     S.kv = (double)kparams[(size_t)b * 3 + 2];
     S.obs = obs + (size_t)b * P.n_obs * 2 * (P.N + 1);
-    if (cpar) {          // ramp-hold refinement pass: centre / span chosen by refine_targets_kernel
+    // ramp-hold targets = base sequence + offset.  Base: the warm start u_ws[b] (the previous solution shifted by one
+    // step, utils.py:354-363 augment_prev_sol) when the scenario carries one (IGT_FLAG_WARM), else u_prev held.
+    S.ws = (cpar.ws && (flags[b] & 2u)) ? cpar.ws + (size_t)b * 2 * P.N : nullptr;
+    if (cpar.cpar) {     // refinement pass: centre offset / span chosen by refine_targets_kernel
 #pragma unroll
-        for (int i = 0; i < 4; ++i) S.cpar[i] = cpar[(size_t)b * 4 + i];
-    } else {             // first pass: centre = u_prev, span = what the rate limits reach over the horizon
-        S.cpar[0] = S.a_prev; S.cpar[1] = S.df_prev;
+        for (int i = 0; i < 4; ++i) S.cpar[i] = cpar.cpar[(size_t)b * 4 + i];
+    } else {             // first pass: offsets centred on 0, span = what the rate limits reach over the horizon
+        S.cpar[0] = 0.0; S.cpar[1] = 0.0;
         S.cpar[2] = P.N * P.rate_a; S.cpar[3] = P.N * P.rate_df;
     }
 }
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(256) void search_kernel(KP P, int B, const T* __res
                                                      const uint32_t* __restrict__ flags,
                                                      const T* __restrict__ obs,
                                                      const double* __restrict__ table,
-                                                     const double* __restrict__ cinf, const double* __restrict__ cpar,
+                                                     const double* __restrict__ cinf, Centre<T> cpar,
                                                      T* __restrict__ cost_out, int32_t* __restrict__ argmin_out,
                                                      int32_t* __restrict__ status_out, T* __restrict__ rec_sN,
                                                      T* __restrict__ rec_vN, double* __restrict__ rec_J,
@@ -124,17 +127,17 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(int B, int W, cons
     status_out[b] = c >= 0 ? 0 : 1;
 }
 
-// Ramp-hold refinement: new candidate centre = the winner's targets, new span = half the distance between
-// the winner's neighbours on the previous grid.  No feasible candidate: parameters are left as they are.
+// Ramp-hold refinement: new centre OFFSET (relative to the base sequence: u_prev held, or the warm start) = the winner's
+// offset, new span = half the distance between the winner's neighbours on the previous grid.  No feasible candidate:
+// parameters are left as they are.
 __global__ __launch_bounds__(256) void refine_targets_kernel(KP P, int B, int W, const double* __restrict__ part_J,
                                                              const int32_t* __restrict__ part_c,
-                                                             const double* __restrict__ u_prev_d,
                                                              double* __restrict__ cpar, int first) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     double ca, cd, sa, sd;
     if (first) {   // parameters of the first pass (load_scenario's defaults)
-        ca = u_prev_d[(size_t)b * 2 + 0]; cd = u_prev_d[(size_t)b * 2 + 1];
+        ca = 0.0; cd = 0.0;
         sa = P.N * P.rate_a; sd = P.N * P.rate_df;
     } else {
         ca = cpar[(size_t)b * 4 + 0]; cd = cpar[(size_t)b * 4 + 1]; sa = cpar[(size_t)b * 4 + 2]; sd = cpar[(size_t)b * 4 + 3];
@@ -151,19 +154,13 @@ __global__ __launch_bounds__(256) void refine_targets_kernel(KP P, int B, int W,
         const int ilo = i > 0 ? i - 1 : i, ihi = i < G - 1 ? i + 1 : i;
         const int jlo = j > 0 ? j - 1 : j, jhi = j < G - 1 ? j + 1 : j;
         const bool f = first != 0;
-        const double na = clampd(ca + cand_m(i, G, f) * sa, P.a_min, P.a_max);
-        const double nd = clampd(cd + cand_m(j, G, f) * sd, -P.df_max, P.df_max);
+        const double na = ca + cand_m(i, G, f) * sa;
+        const double nd = cd + cand_m(j, G, f) * sd;
         sa = sa * (cand_m(ihi, G, f) - cand_m(ilo, G, f)) / (double)(ihi - ilo > 1 ? 2 : 1);
         sd = sd * (cand_m(jhi, G, f) - cand_m(jlo, G, f)) / (double)(jhi - jlo > 1 ? 2 : 1);
         ca = na; cd = nd;
     }
     cpar[(size_t)b * 4 + 0] = ca; cpar[(size_t)b * 4 + 1] = cd; cpar[(size_t)b * 4 + 2] = sa; cpar[(size_t)b * 4 + 3] = sd;
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void to_double_kernel(size_t n, const T* __restrict__ in, double* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (double)in[i];
 }
 
 template <typename T>
@@ -188,7 +185,7 @@ __global__ __launch_bounds__(64) void emit_kernel(KP P, int B, const T* __restri
                                                   const T* __restrict__ u_prev, const T* __restrict__ kparams,
                                                   const uint32_t* __restrict__ flags, const T* __restrict__ obs,
                                                   const double* __restrict__ table,
-                                                  const double* __restrict__ cinf, const double* __restrict__ cpar,
+                                                  const double* __restrict__ cinf, Centre<T> cpar,
                                                   const int32_t* __restrict__ argmin, T* __restrict__ x_out,
                                                   T* __restrict__ u_out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -218,7 +215,7 @@ __global__ __launch_bounds__(256) void rollout_all_kernel(KP P, int B, const T* 
                                                           const uint32_t* __restrict__ flags,
                                                           const T* __restrict__ obs,
                                                           const double* __restrict__ table,
-                                                          const double* __restrict__ cinf, const double* __restrict__ cpar, T* __restrict__ X_all,
+                                                          const double* __restrict__ cinf, Centre<T> cpar, T* __restrict__ X_all,
                                                           T* __restrict__ U_all, T* __restrict__ cost_all,
                                                           uint32_t* __restrict__ viol_all, T* __restrict__ rec_sN,
                                                           T* __restrict__ rec_vN, double* __restrict__ rec_J,
@@ -315,7 +312,7 @@ __device__ __forceinline__ void search_unit(const KP& P, int W, int b, int p, do
                                             const float* __restrict__ u_prev, const float* __restrict__ kparams,
                                             const uint32_t* __restrict__ flags, const float* __restrict__ obs,
                                             const double* __restrict__ table, const double* __restrict__ cinf,
-                                            const double* __restrict__ cpar, double* __restrict__ part_J,
+                                            Centre<float> cpar, double* __restrict__ part_J,
                                             int32_t* __restrict__ part_c, float* __restrict__ rec_sN,
                                             float* __restrict__ rec_vN, double* __restrict__ rec_J,
                                             uint32_t* __restrict__ rec_viol, unsigned* __restrict__ rec_count,
@@ -510,7 +507,7 @@ __device__ __forceinline__ void search_waves(const KP& P, int B, int W, int queu
         int order_stride, double* __restrict__ ckpt, int ck_parts, const float* __restrict__ x0,                        \
         const float* __restrict__ u_prev, const float* __restrict__ kparams, const uint32_t* __restrict__ flags,     \
         const float* __restrict__ obs, const double* __restrict__ table, const double* __restrict__ cinf,            \
-        const double* __restrict__ cpar, double* __restrict__ part_J, int32_t* __restrict__ part_c,                  \
+        Centre<float> cpar, double* __restrict__ part_J, int32_t* __restrict__ part_c,                  \
         float* __restrict__ rec_sN, float* __restrict__ rec_vN, double* __restrict__ rec_J,                          \
         uint32_t* __restrict__ rec_viol, unsigned* __restrict__ rec_count, int32_t* __restrict__ rec_b
 #define IGT_SEARCH_PASS                                                                                              \
@@ -543,7 +540,7 @@ __global__ __launch_bounds__(64) void emit_fast_kernel(KP P, int B, int W, const
                                                        const uint32_t* __restrict__ flags,
                                                        const float* __restrict__ obs,
                                                        const double* __restrict__ table,
-                                                       const double* __restrict__ cinf, const double* __restrict__ cpar,
+                                                       const double* __restrict__ cinf, Centre<float> cpar,
                                                        const double* __restrict__ part_J,
                                                        const int32_t* __restrict__ part_c,
                                                        float* __restrict__ cost_out, int32_t* __restrict__ argmin_out,
@@ -590,7 +587,7 @@ __global__ __launch_bounds__(64) void emit_seg_kernel(KP P, int B, int W, int Wk
                                                       const uint32_t* __restrict__ flags,
                                                       const float* __restrict__ obs,
                                                       const double* __restrict__ table,
-                                                      const double* __restrict__ cinf, const double* __restrict__ cpar,
+                                                      const double* __restrict__ cinf, Centre<float> cpar,
                                                       const double* __restrict__ part_J,
                                                       const int32_t* __restrict__ part_c,
                                                       const double* __restrict__ ckpt,
@@ -641,7 +638,7 @@ __global__ __launch_bounds__(256) void rollout_all_fast_kernel(KP P, int B, cons
                                                                const uint32_t* __restrict__ flags,
                                                                const float* __restrict__ obs,
                                                                const double* __restrict__ table,
-                                                               const double* __restrict__ cinf, const double* __restrict__ cpar,
+                                                               const double* __restrict__ cinf, Centre<float> cpar,
                                                                float* __restrict__ X_all, float* __restrict__ U_all,
                                                                float* __restrict__ cost_all,
                                                                uint32_t* __restrict__ viol_all,
@@ -701,7 +698,7 @@ __device__ __forceinline__ int slice_candidate64(const KP& P, int W, int p, int 
     KP P, int B, int W, int queues, unsigned* __restrict__ work_counter, const unsigned* __restrict__ order,          \
         int order_stride, const double* __restrict__ x0, const double* __restrict__ u_prev,                          \
         const double* __restrict__ kparams, const uint32_t* __restrict__ flags, const double* __restrict__ obs,      \
-        const double* __restrict__ table, const double* __restrict__ cinf, const double* __restrict__ cpar,          \
+        const double* __restrict__ table, const double* __restrict__ cinf, Centre<double> cpar,          \
         double* __restrict__ part_J, int32_t* __restrict__ part_c, double* __restrict__ rec_sN,                      \
         double* __restrict__ rec_vN, double* __restrict__ rec_J, uint32_t* __restrict__ rec_viol
 
@@ -712,7 +709,7 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
                                               const double* __restrict__ u_prev, const double* __restrict__ kparams,
                                               const uint32_t* __restrict__ flags, const double* __restrict__ obs,
                                               const double* __restrict__ table, const double* __restrict__ cinf,
-                                              const double* __restrict__ cpar, double* __restrict__ part_J,
+                                              Centre<double> cpar, double* __restrict__ part_J,
                                               int32_t* __restrict__ part_c, double* __restrict__ rec_sN,
                                               double* __restrict__ rec_vN, double* __restrict__ rec_J,
                                               uint32_t* __restrict__ rec_viol) {
@@ -766,7 +763,7 @@ __global__ __launch_bounds__(64) void emit_f64_kernel(KP P, int B, int W, const 
                                                       const double* __restrict__ kparams,
                                                       const uint32_t* __restrict__ flags, const double* __restrict__ obs,
                                                       const double* __restrict__ table, const double* __restrict__ cinf,
-                                                      const double* __restrict__ cpar, const double* __restrict__ part_J,
+                                                      Centre<double> cpar, const double* __restrict__ part_J,
                                                       const int32_t* __restrict__ part_c, double* __restrict__ cost_out,
                                                       int32_t* __restrict__ argmin_out, int32_t* __restrict__ status_out,
                                                       double* __restrict__ x_out, double* __restrict__ u_out) {
@@ -804,7 +801,7 @@ __global__ __launch_bounds__(256) void rollout_all_f64_kernel(KP P, int B, const
                                                               const uint32_t* __restrict__ flags,
                                                               const double* __restrict__ obs,
                                                               const double* __restrict__ table,
-                                                              const double* __restrict__ cinf, const double* __restrict__ cpar,
+                                                              const double* __restrict__ cinf, Centre<double> cpar,
                                                               double* __restrict__ X_all, double* __restrict__ U_all,
                                                               double* __restrict__ cost_all, uint32_t* __restrict__ viol_all,
                                                               double* __restrict__ rec_sN, double* __restrict__ rec_vN,
@@ -959,6 +956,7 @@ __global__ __launch_bounds__(256) void frenet_step_fast_kernel(KP P, int n, cons
     S.a_prev = 0.0; S.df_prev = 0.0;
     S.b0 = (double)kparams[(size_t)i * 3 + 0]; S.b1 = (double)kparams[(size_t)i * 3 + 1]; S.kv = (double)kparams[(size_t)i * 3 + 2];
     S.cpar[0] = S.cpar[1] = S.cpar[2] = S.cpar[3] = 0.0;
+    S.ws = nullptr;
     S.obs = nullptr;
     const double tab[2] = {(double)u[(size_t)i * 2 + 0], (double)u[(size_t)i * 2 + 1]};   // table [1 candidate, 2, N = 1]
     float out[7 * 2];
@@ -1008,11 +1006,11 @@ static hipError_t launch_search_exact(const KP& P, int B, const SolveArgs<double
     const dim3 grid((B + 3) / 4), block(256);
     if (P.cand_mode != CAND_TABLE)
         hipLaunchKernelGGL((search_kernel<St, double, 1, true, VALUE>), grid, block, 0, st, P, B, A.x0, A.u_prev,
-                           A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.cost_out, A.argmin_out, A.status_out,
+                           A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.cost_out, A.argmin_out, A.status_out,
                            A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
     else
         hipLaunchKernelGGL((search_kernel<St, double, 1, false, VALUE>), grid, block, 0, st, P, B, A.x0, A.u_prev,
-                           A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.cost_out, A.argmin_out, A.status_out,
+                           A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.cost_out, A.argmin_out, A.status_out,
                            A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
     return hipGetLastError();
 }
@@ -1046,15 +1044,15 @@ static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>&
     }
     if (o3)
         hipLaunchKernelGGL((search_fast_kernel_o3<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
-                           order, order_stride, A.ckpt, A.ck_parts, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN,
+                           order, order_stride, A.ckpt, A.ck_parts, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, A.rec_sN,
                            A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
     else if (A.ckpt && A.ck_parts > 1)
         hipLaunchKernelGGL((search_fast_kernel_o2c<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
                            order, order_stride, A.ckpt, A.ck_parts, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf,
-                           A.cpar, A.part_J, A.part_c, A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
+                           A.centre(), A.part_J, A.part_c, A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
     else
         hipLaunchKernelGGL((search_fast_kernel_o2<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
-                           order, order_stride, A.ckpt, A.ck_parts, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.rec_sN,
+                           order, order_stride, A.ckpt, A.ck_parts, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, A.rec_sN,
                            A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
     return hipGetLastError();
 }
@@ -1093,11 +1091,11 @@ static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A
     }
     if (o3)
         hipLaunchKernelGGL((search_f64_kernel_o3<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter, order,
-                           order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c,
+                           order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c,
                            A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
     else
         hipLaunchKernelGGL((search_f64_kernel_o2<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter, order,
-                           order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c,
+                           order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c,
                            A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
     return hipGetLastError();
 }
@@ -1187,20 +1185,12 @@ hipError_t launch_value<float>(const KP& P, int B, const DevNet<float>& net, con
 }
 
 template <typename T>
-hipError_t launch_refine(const KP& P, int B, int W, const SolveArgs<T>& A, double* u_prev_d, double* cpar, int first,
-                         hipStream_t st) {
-    if (first) {
-        hipLaunchKernelGGL((to_double_kernel<T>), dim3(((size_t)B * 2 + 255) / 256), dim3(256), 0, st, (size_t)B * 2, A.u_prev,
-                           u_prev_d);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(refine_targets_kernel, dim3((B + 255) / 256), dim3(256), 0, st, P, B, W, A.part_J, A.part_c, u_prev_d,
-                       cpar, first);
+hipError_t launch_refine(const KP& P, int B, int W, const SolveArgs<T>& A, double* cpar, int first, hipStream_t st) {
+    hipLaunchKernelGGL(refine_targets_kernel, dim3((B + 255) / 256), dim3(256), 0, st, P, B, W, A.part_J, A.part_c, cpar, first);
     return hipGetLastError();
 }
-template hipError_t launch_refine<float>(const KP&, int, int, const SolveArgs<float>&, double*, double*, int, hipStream_t);
-template hipError_t launch_refine<double>(const KP&, int, int, const SolveArgs<double>&, double*, double*, int, hipStream_t);
+template hipError_t launch_refine<float>(const KP&, int, int, const SolveArgs<float>&, double*, int, hipStream_t);
+template hipError_t launch_refine<double>(const KP&, int, int, const SolveArgs<double>&, double*, int, hipStream_t);
 
 template <typename T>
 hipError_t launch_reduce(int B, int W, const SolveArgs<T>& A, hipStream_t st) {
@@ -1217,12 +1207,12 @@ static hipError_t launch_emit_fast(const KP& P, int B, int W, const SolveArgs<fl
         const int Wk = (P.C + 127) / 128;
         hipLaunchKernelGGL((emit_seg_kernel<CAND, HI>), dim3(((size_t)B * A.ck_parts + 63) / 64), dim3(64), 0, st, P, B, W, Wk,
                            A.ck_parts,
-                           A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.ckpt,
+                           A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, A.ckpt,
                            A.cost_out, A.argmin_out, A.status_out, A.x_out, A.u_out);
         return hipGetLastError();
     }
     hipLaunchKernelGGL((emit_fast_kernel<CAND, HI>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, W, A.x0, A.u_prev,
-                       A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.cost_out, A.argmin_out,
+                       A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, A.cost_out, A.argmin_out,
                        A.status_out, A.x_out, A.u_out);
     return hipGetLastError();
 }
@@ -1241,7 +1231,7 @@ hipError_t launch_emit<float>(const KP& P, int B, int W, const SolveArgs<float>&
 template <int CAND, bool HI>
 static hipError_t launch_emit64(const KP& P, int B, int W, const SolveArgs<double>& A, hipStream_t st) {
     hipLaunchKernelGGL((emit_f64_kernel<CAND, HI>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, W, A.x0, A.u_prev, A.kparams,
-                       A.flags, A.obs, A.table, A.cinf, A.cpar, A.part_J, A.part_c, A.cost_out, A.argmin_out, A.status_out,
+                       A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, A.cost_out, A.argmin_out, A.status_out,
                        A.x_out, A.u_out);
     return hipGetLastError();
 }
@@ -1249,7 +1239,7 @@ template <>
 hipError_t launch_emit<double>(const KP& P, int B, int W, const SolveArgs<double>& A, hipStream_t st) {
     if (P.dev & 1024) {     // developer switch: oracle-order kernels (argmin_out is already final there)
         hipLaunchKernelGGL((emit_kernel<ExactStepper<double>, double>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, A.x0,
-                           A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, A.argmin_out, A.x_out, A.u_out);
+                           A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.argmin_out, A.x_out, A.u_out);
         return hipGetLastError();
     }
     if (P.hi_order) {
@@ -1266,7 +1256,7 @@ template <int CAND, bool HI>
 static hipError_t launch_rollout_all_fast(const KP& P, int B, const SolveArgs<float>& A, float* X_all, float* U_all,
                                           float* cost_all, uint32_t* viol_all, hipStream_t st) {
     hipLaunchKernelGGL((rollout_all_fast_kernel<CAND, HI>), dim3((B + 3) / 4), dim3(256), 0, st, P, B, A.x0, A.u_prev,
-                       A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, X_all, U_all, cost_all, viol_all, A.rec_sN, A.rec_vN,
+                       A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), X_all, U_all, cost_all, viol_all, A.rec_sN, A.rec_vN,
                        A.rec_J, A.rec_viol);
     return hipGetLastError();
 }
@@ -1286,7 +1276,7 @@ template <int CAND, bool HI>
 static hipError_t launch_rollout_all64(const KP& P, int B, const SolveArgs<double>& A, double* X_all, double* U_all,
                                        double* cost_all, uint32_t* viol_all, hipStream_t st) {
     hipLaunchKernelGGL((rollout_all_f64_kernel<CAND, HI>), dim3((B + 3) / 4), dim3(256), 0, st, P, B, A.x0, A.u_prev,
-                       A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, X_all, U_all, cost_all, viol_all, A.rec_sN, A.rec_vN,
+                       A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), X_all, U_all, cost_all, viol_all, A.rec_sN, A.rec_vN,
                        A.rec_J, A.rec_viol);
     return hipGetLastError();
 }
@@ -1295,7 +1285,7 @@ hipError_t launch_rollout_all<double>(const KP& P, int B, const SolveArgs<double
                                       double* cost_all, uint32_t* viol_all, hipStream_t st) {
     if (P.dev & 1024) {     // developer switch: oracle-order kernels
         hipLaunchKernelGGL((rollout_all_kernel<ExactStepper<double>, double>), dim3((B + 3) / 4), dim3(256), 0, st, P, B,
-                           A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.cpar, X_all, U_all, cost_all, viol_all,
+                           A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), X_all, U_all, cost_all, viol_all,
                            A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
         return hipGetLastError();
     }

@@ -18,7 +18,9 @@ struct SolveArgs {   // all device pointers
     const T* enc;
     const double* table;   // [C,2,N] or null
     const double* cinf;    // [F,3] or null
-    const double* cpar;    // [B,4] ramp-hold centre/span of a refinement pass, or null (first pass)
+    const double* cpar;    // [B,4] ramp-hold centre offset / span of a refinement pass, or null (first pass)
+    const T* u_ws;         // [B,2,N] warm start (previous solution shifted by one step), or null; used where flags & 2
+    Centre<T> centre() const { return Centre<T>{cpar, u_ws}; }
     T* x_out;
     T* u_out;
     T* cost_out;
@@ -56,8 +58,7 @@ hipError_t prepare_value_kernels(int n_hidden_mats);   // once per igt_set_value
 template <typename T> hipError_t launch_reduce(int B, int W, const SolveArgs<T>& A, hipStream_t st);
 // ramp-hold refinement: winner of the pass just finished -> centre/span of the next pass (cpar[B,4])
 template <typename T>
-hipError_t launch_refine(const KP& P, int B, int W, const SolveArgs<T>& A, double* u_prev_d, double* cpar, int first,
-                         hipStream_t st);
+hipError_t launch_refine(const KP& P, int B, int W, const SolveArgs<T>& A, double* cpar, int first, hipStream_t st);
 template <typename T>
 hipError_t launch_rollout_all(const KP& P, int B, const SolveArgs<T>& A, T* X_all, T* U_all, T* cost_all,
                               uint32_t* viol_all, hipStream_t st);   // value mode: also fills A.rec_*

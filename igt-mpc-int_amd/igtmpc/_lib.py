@@ -12,6 +12,7 @@ IGT_MEM_DEVICE, IGT_MEM_HOST = 0, 1
 IGT_CAND_LATTICE, IGT_CAND_TABLE, IGT_CAND_RAMP_HOLD = 0, 1, 2
 IGT_COST_PROGRESS, IGT_COST_VALUE_NET = 0, 1
 IGT_FLAG_ABS_HEADING = 1
+IGT_FLAG_WARM = 2
 VIOL_BITS = dict(box_v=1, box_u=2, rate=4, ey=8, terminal=16, collision=32, nonfinite=64)
 
 
@@ -29,6 +30,8 @@ class igt_params(C.Structure):
 _vp, _i32, _i = C.c_void_p, C.c_int32, C.c_int
 _SOLVE = [_vp, _i32] + [_vp] * 12 + [_i, _vp]
 _ROLL = [_vp, _i32] + [_vp] * 11 + [_i, _vp]
+_SOLVE_WS = [_vp, _i32] + [_vp] * 13 + [_i, _vp]
+_ROLL_WS = [_vp, _i32] + [_vp] * 12 + [_i, _vp]
 _CART = [_vp, _i32, _i32, _vp, _vp, _vp, _i, _vp]
 _FSTEP = [_vp, _i32, _vp, _vp, _vp, _vp, _i, _vp]
 _FCAST = [_vp, _i32] + [_vp] * 9 + [_i, _vp]
@@ -44,8 +47,12 @@ SYMBOLS = {
     'igt_set_value_net': (_i, [_vp, _i32, _vp, _vp, _vp, _vp, C.c_double, C.c_double]),
     'igt_solve_batch_f32': (_i, _SOLVE),
     'igt_solve_batch_f64': (_i, _SOLVE),
+    'igt_solve_batch_ws_f32': (_i, _SOLVE_WS),
+    'igt_solve_batch_ws_f64': (_i, _SOLVE_WS),
     'igt_rollout_batch_f32': (_i, _ROLL),
     'igt_rollout_batch_f64': (_i, _ROLL),
+    'igt_rollout_batch_ws_f32': (_i, _ROLL_WS),
+    'igt_rollout_batch_ws_f64': (_i, _ROLL_WS),
     'igt_set_routes': (_i, [_vp, _i32, _vp]),
     'igt_forecast_batch_f32': (_i, _FCAST),
     'igt_forecast_batch_f64': (_i, _FCAST),

@@ -22,6 +22,7 @@ import numpy as np
 
 from . import routes as R
 from .cinf import cinf_halfplanes
+from ._lib import IGT_FLAG_WARM
 from .solver import BatchSolver
 
 A_MIN_POLICY = -4.0        # mpc.yaml:8, used by the brake fallback (evaluate.py:514)
@@ -48,19 +49,29 @@ def initial_states(rng, route_pairs):
 
 def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=256, n_rk4=4, device=0,
                     dtype='f32', rotation=None, cand_mode='ramp_hold', refine_iters=0, verbose=False,
-                    eval_mode='mpc', value_net=None, device_resident=False):
+                    eval_mode='mpc', value_net=None, device_resident=False, warm_start=True, init=None):
     """eval_mode 'mpc' (evaluate.py:370-639) or 'gt_mpc' (123-369: terminal value network in the cost; needs
     value_net = dict(layers=[(W,b),...][, Wn, mu_f, sigma_t, mu_t]) -- the reference's normalisation statistics are
     not shipped, identity by default).  device_resident=True keeps every per-step array in HBM (torch tensors;
-    forecast, solve, fallback step and the state update never leave the GPU) -- for thousands of episodes."""
+    forecast, solve, fallback step and the state update never leave the GPU) -- for thousands of episodes.
+    warm_start (ramp-hold candidates): an agent that solved the previous step centres its candidates on that solution
+    shifted by one step (evaluate.py:478-481, utils.py:354-363 augment_prev_sol) instead of on u_prev held.
+    init = (x[E,M,7], route_pairs[E]) overrides the sampled initial states."""
     gt = eval_mode == 'gt_mpc'
     if gt and value_net is None:
         raise ValueError("eval_mode='gt_mpc' needs value_net")
     rng = np.random.default_rng(seed)                                   # evaluate.py:35, 56
-    E, M = num_samples, 2
-    M_sim = int(T_sim / dt)                                             # evaluate.py:83-84
-    pairs = [R.SCENARIO_ROUTES[sc - 1][(e if rotation is None else rotation) % 4] for e in range(E)]
-    x, rid = initial_states(rng, pairs)                                 # x[E,M,7]
+    M = 2
+    M_sim = int(round(T_sim / dt))                                      # evaluate.py:83-84
+    if init is not None:
+        x, pairs = np.array(init[0], dtype=np.float64), [tuple(p) for p in init[1]]
+        E = num_samples = len(pairs)
+        rid = np.array([[R.ROUTE_ID[r] for r in p] for p in pairs], dtype=np.int64)
+    else:
+        E = num_samples
+        pairs = [R.SCENARIO_ROUTES[sc - 1][(e if rotation is None else rotation) % 4] for e in range(E)]
+        x, rid = initial_states(rng, pairs)                             # x[E,M,7]
+    warm = bool(warm_start) and cand_mode == 'ramp_hold'
     kp = R.kparams(rid)                                                 # [E,M,3]
     absh = R.TABLES['abs_heading'][rid]
     flags = absh.astype(np.uint32).reshape(-1)
@@ -82,7 +93,7 @@ def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=
     npdt = solver.np_dtype
 
     if device_resident:
-        out = _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc if gt else None, gt, E, M, N, M_sim, device)
+        out = _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc if gt else None, gt, E, M, N, M_sim, device, warm)
         solver.close()
         stepper.close()
         out['routes'] = pairs
@@ -111,11 +122,16 @@ def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=
                                    sol_x[:, other].reshape(E * M, 7, N + 1).astype(npdt),
                                    sol_u[:, other].reshape(E * M, 2, N).astype(npdt),
                                    (have_sol[:, other] & (t > 0)).reshape(-1).astype(np.int32))
-        # --- solve every (episode, agent) problem at once (evaluate.py:470-482)
+        # --- solve every (episode, agent) problem at once (evaluate.py:470-482); an agent that solved the previous
+        #     step passes that solution, shifted by one step, as its warm start (evaluate.py:478-481)
         t0 = time.perf_counter()
+        fl, u_ws = flags, None
+        if warm and t > 0:
+            fl = flags | np.where(have_sol.reshape(-1), IGT_FLAG_WARM, 0).astype(np.uint32)
+            u_ws = shift_controls(sol_u).reshape(E * M, 2, N).astype(npdt)
         out = solver.solve(x.reshape(E * M, 7).astype(npdt), u_prev.reshape(E * M, 2).astype(npdt),
-                           kp.reshape(E * M, 3).astype(npdt), flags, obs,
-                           tv if gt else None, enc.astype(npdt) if gt else None)
+                           kp.reshape(E * M, 3).astype(npdt), fl, obs,
+                           tv if gt else None, enc.astype(npdt) if gt else None, u_ws=u_ws)
         solve_ms.append((time.perf_counter() - t0) * 1e3)
         ok = (out['status'] == 0).reshape(E, M)
         xs = out['x'].reshape(E, M, 7, N + 1).astype(np.float64)
@@ -147,7 +163,15 @@ def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=
                 routes=pairs, solve_ms=np.array(solve_ms))
 
 
-def _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc, gt, E, M, N, M_sim, device):
+def shift_controls(u):
+    """Control part of utils.py:354-363 augment_prev_sol: u[...,2,N] -> [u[..., 1:], u[..., -1:]] (numpy or torch)."""
+    if isinstance(u, np.ndarray):
+        return np.concatenate([u[..., 1:], u[..., -1:]], axis=-1)
+    import torch
+    return torch.cat([u[..., 1:], u[..., -1:]], dim=-1)
+
+
+def _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc, gt, E, M, N, M_sim, device, warm):
     """The same time loop with every array resident in HBM (float64 state, solver-dtype views per call)."""
     import torch
     dev = torch.device('cuda', device)
@@ -181,8 +205,12 @@ def _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc, gt, E, M, N, M
                                   a_fc.reshape(-1).to(td).contiguous(), rid_o,
                                   sol_x.flip(1).reshape(E * M, 7, N + 1).contiguous(),
                                   sol_u.flip(1).reshape(E * M, 2, N).contiguous(), hp)
+        fl, u_ws = flags_t, None
+        if warm and t > 0:
+            fl = flags_t | (have_sol.reshape(-1).to(torch.int32) * IGT_FLAG_WARM)
+            u_ws = shift_controls(sol_u).reshape(E * M, 2, N).contiguous()
         out = solver.solve(x.reshape(E * M, 7).to(td).contiguous(), u_prev.reshape(E * M, 2).to(td).contiguous(), kp_s,
-                           flags_t, obs, tv if gt else None, enc_t)
+                           fl, obs, tv if gt else None, enc_t, u_ws=u_ws)
         ok = (out['status'] == 0).reshape(E, M)
         xs = out['x'].reshape(E, M, 7, N + 1)
         us = out['u'].reshape(E, M, 2, N)

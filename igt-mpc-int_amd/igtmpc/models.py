@@ -23,8 +23,9 @@ def _kparams(K):
         return Curvature().kparams
     if hasattr(K, 'kparams'):
         return K.kparams
-    raise TypeError('state.K must be an igtmpc.Curvature (it carries the break-points the GPU model needs); '
-                    'build it with Curvature.from_route(route) or Curvature.from_reference(ref["K"], route)')
+    if callable(K):     # any K(s) of the reference's shape (evaluate.py:384-402): probed once for (b0, b1, Kv)
+        return Curvature.from_callable(K).kparams
+    raise TypeError('state.K must be None, 0, an igtmpc.Curvature or a callable piecewise-constant K(s)')
 
 
 class KinematicBicycleModelFrenet:

@@ -7,15 +7,43 @@ per (scenario, ego) problem on the MI355X) and returns the feasible arg-min of t
 Planners created with the same discretisation share one solver handle per device; the batched
 entry (`BatchSolver.solve`) is the throughput path, this class is the per-agent compatibility face.
 """
+import hashlib
 import time
 
 import numpy as np
 
 from .cinf import cinf_halfplanes
+from ._lib import IGT_FLAG_WARM
 from .solver import BatchSolver
 from .vehicle import Curvature, VehicleAction, VehicleReference  # noqa: F401  (re-exported for drivers)
 
 _SHARED = {}
+
+
+def _net_digest(value_net):
+    if value_net is None:
+        return None
+    h = hashlib.sha256()
+    for W, b in value_net['layers']:
+        h.update(np.ascontiguousarray(W, dtype=np.float64).tobytes())
+        h.update(np.ascontiguousarray(b, dtype=np.float64).tobytes())
+    for k in ('Wn', 'mu_f', 'sigma_t', 'mu_t'):
+        if value_net.get(k) is not None:
+            h.update(np.ascontiguousarray(value_net[k], dtype=np.float64).tobytes())
+    return h.hexdigest()
+
+
+def augment_prev_sol(data, model, K):
+    """utils.py:354-363: previous solution (x[7,N+1], u[2,N]) -> warm start of the next solve: shifted by one step, the
+    states extended by one model step with the last control (retried with a = 0 when that step ends above v = 5,
+    v clipped to [-1, 5]), the controls by repeating the last one."""
+    x_sol_prev, u_sol_prev = np.asarray(data[0], dtype=np.float64), np.asarray(data[1], dtype=np.float64)
+    last = dict(zip(('x', 'y', 's', 'ey', 'epsi', 'v', 'heading'), x_sol_prev[:, -1]), K=K)
+    nxt = model(VehicleReference(last), VehicleAction({'a': u_sol_prev[0, -1], 'df': u_sol_prev[1, -1]}))
+    if nxt.v > 5:
+        nxt = model(VehicleReference(last), VehicleAction({'a': 0, 'df': u_sol_prev[1, -1]}))
+    col = np.array([[nxt.x], [nxt.y], [nxt.s], [nxt.ey], [nxt.epsi], [np.clip(nxt.v, -1, 5)], [nxt.heading]])
+    return (np.hstack([x_sol_prev[:, 1:], col]), np.hstack([u_sol_prev[:, 1:], u_sol_prev[:, [-1]]]))
 
 
 class _Stats:
@@ -33,7 +61,7 @@ class MPC_Planner:
     def __init__(self, N=10, dt=0.1, agents=None, goals=None, ca_radius=2.8, ref=None, road_dim=(10, 50),
                  routes=None, ds_right=None, index=None, num_rk4_steps=7, solver='ipopt', ca_type='circle',
                  nn_config_dir=None, use_NN_cost2go=False, weights=(1, 1, 1),
-                 C=256, device=0, dtype='f32', value_net=None):
+                 C=256, device=0, dtype='f64', value_net=None, cand_mode='ramp_hold', refine_iters=0):
         assert agents is not None, 'Agents are not defined'           # mpc.py:155
         assert index is not None                                      # mpc.py:80
         if ca_type != 'circle':
@@ -70,10 +98,15 @@ class MPC_Planner:
         # terminal set (mpc.py:88-104) -- same for every planner with this dt
         self.C_inf = cinf_halfplanes(dt=dt, jerk=self.jerk_limit)
         cost_mode = 'value_net' if use_NN_cost2go else 'progress'
-        key = (N, dt, num_rk4_steps, C, self.num_obstacles, device, dtype, cost_mode, self.d_min, id(value_net))
+        self.cand_mode = cand_mode
+        # planners with the same discretisation, candidate family and value network share one solver handle; the
+        # network is keyed by CONTENT (a dict rebuilt with the same weights maps to the same handle)
+        key = (N, dt, num_rk4_steps, C, self.num_obstacles, device, dtype, cost_mode, self.d_min, cand_mode, refine_iters,
+               _net_digest(value_net))
         if key not in _SHARED:
             s = BatchSolver(N=N, dt=dt, n_rk4=num_rk4_steps, C=C, n_obs=self.num_obstacles, device=device,
-                            dtype=dtype, cost_mode=cost_mode, d_min=self.d_min)
+                            dtype=dtype, cost_mode=cost_mode, d_min=self.d_min, cand_mode=cand_mode,
+                            refine_iters=refine_iters)
             s.set_cinf(*self.C_inf)
             if use_NN_cost2go:
                 if value_net is None:
@@ -128,13 +161,19 @@ class MPC_Planner:
     # ------------------------------------------------------------------ mpc.py:383-406
     def solve(self, x_sol_prev=None, u_sol_prev=None):
         """-> (x[7,N+1], u[2,N], True) or (None, None, False); never raises on an infeasible problem.
-        The warm start of the NLP has no counterpart in sampled shooting and is ignored."""
+        u_sol_prev[2,N] -- what evaluate.py:478-482 passes after augment_prev_sol -- is the warm start: IPOPT started
+        its iterations there (mpc.py:386-389), the shooting solver centres its ramp-hold candidates there, so the
+        shifted previous plan is itself one of the candidates.  x_sol_prev has no counterpart (states are implied)."""
         flags = np.array([1 if self._abs_heading[self.ind] else 0], dtype=np.uint32)
         kp = np.array([self.K.kparams], dtype=self._dt)
+        u_ws = None
+        if u_sol_prev is not None and self.cand_mode == 'ramp_hold':
+            u_ws = np.ascontiguousarray(np.asarray(u_sol_prev, dtype=self._dt).reshape(1, 2, self.N))
+            flags = flags | np.uint32(IGT_FLAG_WARM)
         t0 = time.time()
         out = self._solver.solve(self._x0, self._u_prev, kp, flags, self._obs,
                                  self._tv_sv if self.use_NN_cost2go else None,
-                                 self._enc if self.use_NN_cost2go else None)
+                                 self._enc if self.use_NN_cost2go else None, u_ws=u_ws)
         self.solve_time = time.time() - t0
         status = int(out['status'][0])
         self.sol = _Stats(self.solve_time, status, float(out['cost'][0]), int(out['argmin'][0]))
@@ -145,5 +184,20 @@ class MPC_Planner:
         self.x_sol_prev = x
         return (x, u, True)
 
+    def CAV_utility(self, x, u):
+        """mpc.py:356-373 on a trajectory (x[7,N+1], u[2,N]) in float64 on the host -- the expression the kernels
+        evaluate per candidate (progress cost; the value-net term lives on the device only)."""
+        x, u = np.asarray(x, dtype=np.float64), np.asarray(u, dtype=np.float64)
+        J = 0.0
+        for k in range(self.N + 1):
+            if k < self.N:
+                J = J + 0.05 * (u[0, k] ** 2 + u[1, k] ** 2)           # mpc.py:362
+            J = J + x[4, k] ** 2                                        # mpc.py:363
+            J = J + x[3, k] ** 2                                        # mpc.py:364
+        return J - (x[2, self.N] - x[2, 0])                             # mpc.py:372
+
     def cost_function(self):
-        raise NotImplementedError('the cost is evaluated inside the kernels (csrc/igt_device.h); see CAV_utility there')
+        """mpc.py:375-376 returns the CasADi expression of the cost; here: the cost of the last solution."""
+        if self.sol is None:
+            raise RuntimeError('cost_function() needs a solve first')
+        return self.sol.stats()['cost']

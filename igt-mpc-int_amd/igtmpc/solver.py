@@ -45,8 +45,8 @@ class BatchSolver:
         L.check(self.lib.igt_create(ct.byref(p), device, ct.byref(h)))
         self._h = h
         self.N, self.C, self.n_obs = N, C, n_obs
-        self._solve = getattr(self.lib, f'igt_solve_batch_{dtype}')
-        self._rollout = getattr(self.lib, f'igt_rollout_batch_{dtype}')
+        self._solve = getattr(self.lib, f'igt_solve_batch_ws_{dtype}')
+        self._rollout = getattr(self.lib, f'igt_rollout_batch_ws_{dtype}')
         self._cart = getattr(self.lib, f'igt_cartesian_euler_{dtype}')
         self._fstep = getattr(self.lib, f'igt_frenet_step_{dtype}')
         self._fcast = getattr(self.lib, f'igt_forecast_batch_{dtype}')
@@ -166,9 +166,11 @@ class BatchSolver:
         return ptr or None
 
     # ------------------------------------------------------------------ the solve
-    def solve(self, x0, u_prev, kparams, flags, obs_xy=None, tv_sv=None, enc=None, out=None, stream=None):
+    def solve(self, x0, u_prev, kparams, flags, obs_xy=None, tv_sv=None, enc=None, out=None, stream=None, u_ws=None):
         """x0[B,7] u_prev[B,2] kparams[B,3] flags[B] obs_xy[B,n_obs,2,N+1]
-        -> dict(x[B,7,N+1], u[B,2,N], cost[B], argmin[B], status[B])."""
+        -> dict(x[B,7,N+1], u[B,2,N], cost[B], argmin[B], status[B]).
+        u_ws[B,2,N]: warm start (previous solution shifted by one step, utils.py:354-363), read where
+        flags & IGT_FLAG_WARM; ramp-hold candidates are then centred on it instead of on u_prev."""
         B = int(x0.shape[0])
         dt, N, no = self.np_dtype, self.N, self.n_obs
         torch_mode = _is_torch(x0)
@@ -185,21 +187,21 @@ class BatchSolver:
             else:
                 out = dict(x=np.empty((B, 7, N + 1), dt), u=np.empty((B, 2, N), dt), cost=np.empty((B,), dt),
                            argmin=np.empty((B,), np.int32), status=np.empty((B,), np.int32))
-        arrs = [x0, u_prev, kparams, flags, obs_xy, tv_sv, enc,
+        arrs = [x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, u_ws,
                 out['x'], out['u'], out['cost'], out['argmin'], out['status']]
-        shapes = [(B, 7), (B, 2), (B, 3), (B,), (B, no, 2, N + 1), (B, 2), (B, 2),
+        shapes = [(B, 7), (B, 2), (B, 3), (B,), (B, no, 2, N + 1), (B, 2), (B, 2), (B, 2, N),
                   (B, 7, N + 1), (B, 2, N), (B,), (B,), (B,)]
-        dts = [dt, dt, dt, np.uint32, dt, dt, dt, dt, dt, dt, np.int32, np.int32]
+        dts = [dt, dt, dt, np.uint32, dt, dt, dt, dt, dt, dt, dt, np.int32, np.int32]
         mode, ptrs, keep = self._prep(arrs, shapes, dts)
         if mode == L.IGT_MEM_HOST:
-            for k, i in (('x', 7), ('u', 8), ('cost', 9), ('argmin', 10), ('status', 11)):
+            for k, i in (('x', 8), ('u', 9), ('cost', 10), ('argmin', 11), ('status', 12)):
                 if keep_is_copy(out[k], ptrs[i]):
                     raise ValueError(f'out[{k!r}] must be a contiguous array of the solver dtype')
         L.check(self._solve(self._h, B, *ptrs, mode, self._stream_ptr(stream, mode == L.IGT_MEM_DEVICE)))
         return out
 
     def rollout_all(self, x0, u_prev, kparams, flags, obs_xy=None, tv_sv=None, enc=None, want_X=True, want_U=True,
-                    stream=None):
+                    stream=None, u_ws=None):
         """Every candidate of every scenario (parity/debug):
         -> dict(X[B,C,7,N+1] | None, U[B,C,2,N] | None, cost[B,C], viol[B,C])."""
         B = int(x0.shape[0])
@@ -210,10 +212,10 @@ class BatchSolver:
         U = np.empty((B, Cn, 2, N), dt) if want_U else None
         cost = np.empty((B, Cn), dt)
         viol = np.empty((B, Cn), np.uint32)
-        arrs = [x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, X, U, cost, viol]
-        shapes = [(B, 7), (B, 2), (B, 3), (B,), (B, no, 2, N + 1), (B, 2), (B, 2),
+        arrs = [x0, u_prev, kparams, flags, obs_xy, tv_sv, enc, u_ws, X, U, cost, viol]
+        shapes = [(B, 7), (B, 2), (B, 3), (B,), (B, no, 2, N + 1), (B, 2), (B, 2), (B, 2, N),
                   (B, Cn, 7, N + 1), (B, Cn, 2, N), (B, Cn), (B, Cn)]
-        dts = [dt, dt, dt, np.uint32, dt, dt, dt, dt, dt, dt, np.uint32]
+        dts = [dt, dt, dt, np.uint32, dt, dt, dt, dt, dt, dt, dt, np.uint32]
         mode, ptrs, keep = self._prep(arrs, shapes, dts)
         L.check(self._rollout(self._h, B, *ptrs, mode, self._stream_ptr(stream, False)))
         return dict(X=X, U=U, cost=cost, viol=viol)

@@ -81,3 +81,43 @@ class Curvature:
         radius = float(np.max(np.abs(1.0 / K[nz])))
         b0 = (L - W) / 2 if route in ('12', '23', '34', '41') else (L - W) / 2 - ds_right
         return cls(b0, b0 + radius * np.pi / 2, float(K[nz[0]]))
+
+    @classmethod
+    def from_callable(cls, K, s_max=200.0, step=0.05):
+        """Recovers (b0, b1, Kv) from ANY callable curvature K(s) of the reference's shape -- piecewise constant, 0
+        outside one interval [b0, b1) (mpc.py:183-200; evaluate.py:384-402 builds it as a casadi Function) -- by
+        sampling it on a grid and bisecting each jump to the last representable s (the break-points come out exactly
+        as the float64 numbers the callable compares against).  The result is cached on the callable."""
+        cached = getattr(K, '_igt_curvature', None)
+        if cached is not None:
+            return cached
+        f = lambda s: float(K(s))
+        n = int(round(s_max / step))
+        vals = [f(i * step) for i in range(n + 1)]
+        jumps = [i for i in range(n) if vals[i] != vals[i + 1]]
+        if not jumps:
+            if vals[0] != 0.0:
+                raise ValueError('curvature callable is a non-zero constant: not a route of the four-way intersection')
+            out = cls()
+        else:
+            if len(jumps) > 2 or vals[0] != 0.0 or (len(jumps) == 2 and vals[-1] != 0.0):
+                raise ValueError('curvature callable is not 0 / Kv / 0 piecewise constant')
+            bps = []
+            for i in jumps:
+                lo, hi, v_lo = i * step, (i + 1) * step, vals[i]
+                while True:                       # invariant: K(lo) == v_lo != K(hi); ends at adjacent doubles
+                    mid = 0.5 * (lo + hi)
+                    if mid <= lo or mid >= hi:
+                        break
+                    if f(mid) == v_lo:
+                        lo = mid
+                    else:
+                        hi = mid
+                bps.append(hi)                    # first s with the new value: K(s) = Kv for s >= b0
+            kv = vals[jumps[0] + 1]
+            out = cls(bps[0], bps[1] if len(bps) == 2 else float('inf'), kv)
+        try:
+            K._igt_curvature = out
+        except (AttributeError, TypeError):
+            pass
+        return out

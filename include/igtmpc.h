@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IGT_VERSION 100
+#define IGT_VERSION 200
 
 enum {
     IGT_OK = 0,
@@ -51,9 +51,10 @@ enum { IGT_MEM_DEVICE = 0, IGT_MEM_HOST = 1 };
 enum {
     IGT_CAND_LATTICE = 0,  /* G x G lattice of constant per-step (da, ddf) increments */
     IGT_CAND_TABLE = 1,    /* explicit table U[C,2,N] shared by every scenario         */
-    IGT_CAND_RAMP_HOLD = 2 /* G x G: a and df ramp at the rate limits towards one of G targets each and hold
-                              it; targets are dense around u_prev (first pass) and, with refine_iters > 0,
-                              re-centred on the previous pass's winner with the spacing of its grid cell  */
+    IGT_CAND_RAMP_HOLD = 2 /* G x G: a and df track, at the rate limits, base sequence + one of G offsets each; the
+                              base is u_prev held over the horizon or -- igt_solve_batch_ws_* -- the warm start (the
+                              previous solution shifted by one step); offsets are dense around 0 (first pass) and, with
+                              refine_iters > 0, re-centred on the previous pass's winner with its grid cell's spacing */
 };
 
 /* cost (mpc.py:356-373) */
@@ -64,6 +65,7 @@ enum {
 
 /* per-scenario flag bits (flags[B]) */
 #define IGT_FLAG_ABS_HEADING 1u /* ego route in {'32','41'}: psi_0 = |psi_0|  (mpc.py:231-234, 282-285) */
+#define IGT_FLAG_WARM 2u        /* the scenario's row of u_ws holds a warm start (igt_solve_batch_ws_*)          */
 
 /* violation bits reported by igt_rollout_batch_* (viol_out) */
 #define IGT_VIOL_BOX_V 1u      /* mpc.py:316-317  k = 0..N-1 */
@@ -152,9 +154,10 @@ int igt_set_value_net(igt_handle* h, int32_t n_layers, const int32_t* dims, cons
  *        status 0 <-> is_opt True; 1 <-> no feasible candidate (is_opt False,
  *        mpc.py:402-406): then argmin = -1, cost = +inf, x_out/u_out = NaN.
  *
- * _f32: float storage, float derivatives, double state accumulators (the fast
- *       path; within 1e-5*max(1,|ref|) of the float64 oracle).
- * _f64: double everywhere, same operation order as the oracle (parity reference).
+ * _f64: double everywhere -- the reference's precision.  The RK4 stages are evaluated in factorised form
+ *       (csrc/igt_fast64.h); <= 1e-9 of the float64 oracle on every trajectory (measured ~1e-14).
+ * _f32: float storage, float stage derivatives, double state accumulators; within 1e-5*max(1,|ref|) of the
+ *       float64 oracle except where a curvature switch is decided inside float32 noise.
  */
 int igt_solve_batch_f32(igt_handle* h, int32_t B, const float* x0, const float* u_prev,
                         const float* kparams, const uint32_t* flags, const float* obs_xy,
@@ -167,6 +170,25 @@ int igt_solve_batch_f64(igt_handle* h, int32_t B, const double* x0, const double
                         double* cost_out, int32_t* argmin_out, int32_t* status_out, int mem,
                         void* stream);
 
+/* The same solve with a warm start -- what the reference passes to solve(x_sol_prev, u_sol_prev) after
+ * augment_prev_sol (utils.py:354-363; call site evaluate.py:478-482): the previous solution's controls shifted by one
+ * step and extended by repeating the last one.  IPOPT starts its iterations there; the shooting solver centres its
+ * candidate set there: IGT_CAND_RAMP_HOLD targets become u_ws[b,:,k] + offset (instead of u_prev + offset), so the
+ * shifted previous plan is itself candidate (G/2, G/2).  The state part x_sol_prev has no counterpart (shooting states
+ * are implied by the controls).
+ *   u_ws [B,2,N]   rows are read only where flags[b] & IGT_FLAG_WARM; NULL = no warm start anywhere.
+ * Needs cand_mode IGT_CAND_RAMP_HOLD when u_ws != NULL. */
+int igt_solve_batch_ws_f32(igt_handle* h, int32_t B, const float* x0, const float* u_prev,
+                           const float* kparams, const uint32_t* flags, const float* obs_xy,
+                           const float* tv_sv, const float* enc, const float* u_ws, float* x_out,
+                           float* u_out, float* cost_out, int32_t* argmin_out, int32_t* status_out,
+                           int mem, void* stream);
+int igt_solve_batch_ws_f64(igt_handle* h, int32_t B, const double* x0, const double* u_prev,
+                           const double* kparams, const uint32_t* flags, const double* obs_xy,
+                           const double* tv_sv, const double* enc, const double* u_ws, double* x_out,
+                           double* u_out, double* cost_out, int32_t* argmin_out, int32_t* status_out,
+                           int mem, void* stream);
+
 /* Debug / parity entry: every candidate of every scenario.
  *   X_all [B,C,7,N+1] (may be NULL)   U_all [B,C,2,N] (may be NULL)
  *   cost_all [B,C]   viol_all [B,C] (IGT_VIOL_* bits; 0 = feasible) */
@@ -178,6 +200,15 @@ int igt_rollout_batch_f64(igt_handle* h, int32_t B, const double* x0, const doub
                           const double* kparams, const uint32_t* flags, const double* obs_xy,
                           const double* tv_sv, const double* enc, double* X_all, double* U_all,
                           double* cost_all, uint32_t* viol_all, int mem, void* stream);
+
+int igt_rollout_batch_ws_f32(igt_handle* h, int32_t B, const float* x0, const float* u_prev,
+                             const float* kparams, const uint32_t* flags, const float* obs_xy,
+                             const float* tv_sv, const float* enc, const float* u_ws, float* X_all,
+                             float* U_all, float* cost_all, uint32_t* viol_all, int mem, void* stream);
+int igt_rollout_batch_ws_f64(igt_handle* h, int32_t B, const double* x0, const double* u_prev,
+                             const double* kparams, const uint32_t* flags, const double* obs_xy,
+                             const double* tv_sv, const double* enc, const double* u_ws, double* X_all,
+                             double* U_all, double* cost_all, uint32_t* viol_all, int mem, void* stream);
 
 /* One control step of the RK4 Frenet bicycle model for n independent states -- the model
  * object the reference's driver calls directly for warm-start extension and for the

@@ -47,8 +47,22 @@ def test_model_objects_match_reference_models(golden_dir):
     st = igtmpc.VehicleState({'x': c['z'][0, 0], 'y': c['z'][0, 1], 'heading': c['z'][0, 2], 'v': c['z'][0, 3]})
     nx = mc(st, igtmpc.VehicleAction({'a': c['u'][0, 0], 'df': c['u'][0, 1]}))
     assert rel_err([nx.x, nx.y, nx.heading, nx.v], c['z_next'][0]).max() < 1e-12
+    # any callable K(s) of the reference's shape is accepted (evaluate.py:384-402 hands the model a casadi Function):
+    # it is probed once for its break-points, which come out as the exact float64 numbers it compares against
+    i = 1
+    b0, b1, kv = (float(q) for q in g['kp'][i])
+    plain = lambda s: (kv if s >= b0 else 0.0) - (kv if s >= b1 else 0.0)
+    st = {K: igtmpc.VehicleReference(dict(zip(('x', 'y', 's', 'ey', 'epsi', 'v', 'heading'), g['x0'][i]), K=K))
+          for K in (plain, igtmpc.Curvature(b0, b1, kv))}
+    for k in range(3):
+        st = {K: m(v, igtmpc.VehicleAction({'a': g['U'][i, 0, k], 'df': g['U'][i, 1, k]})) for K, v in st.items()}
+    a, b = (v.state7() for v in st.values())
+    assert a == b and rel_err(a, g['X'][i, :, 3]).max() < 1e-12
+    assert igtmpc.Curvature.from_callable(plain).kparams == (b0, b1, kv)
+    zero = m(igtmpc.VehicleReference(dict(x=0, y=0, s=0, ey=0, epsi=0, v=1, heading=0, K=lambda s: 0)), igtmpc.VehicleAction({'a': 0, 'df': 0}))
+    assert abs(zero.s - 0.1) < 1e-12
     with pytest.raises(TypeError):
-        m(igtmpc.VehicleReference(dict(x=0, y=0, s=0, ey=0, epsi=0, v=1, heading=0, K=lambda s: 0)), igtmpc.VehicleAction({'a': 0, 'df': 0}))
+        m(igtmpc.VehicleReference(dict(x=0, y=0, s=0, ey=0, epsi=0, v=1, heading=0, K='left')), igtmpc.VehicleAction({'a': 0, 'df': 0}))
 
 
 def _scene():
@@ -82,11 +96,14 @@ def test_mpc_planner_call_sequence_matches_oracle():
     P = O.Params(N=N)
     for i in range(2):
         pl = igtmpc.MPC_Planner(N=N, dt=0.1, ca_radius=2.8, agents=agents, routes=routes, ref=refs, goals=None,
-                                road_dim=(11.4, 50), ds_right=8.6, index=i, num_rk4_steps=4, dtype='f64')
+                                road_dim=(11.4, 50), ds_right=8.6, index=i, num_rk4_steps=4, dtype='f64',
+                                cand_mode='lattice')
         pl.update_initial_condition(agents[i], inputs[i])
         pl.update_predictions(preds, raw_preds=preds)
         x, u, ok = pl.solve()
         assert pl.solve_time > 0 and pl.NN_query_time == -1 and 't_wall_total' in pl.sol.stats()
+        if ok:
+            assert abs(pl.cost_function() - pl.CAV_utility(x, u)) < 1e-9
         st = agents[i]['state']
         x0 = np.array([st.state7()])
         obs = np.array([[[[p.x for p in preds[1 - i]], [p.y for p in preds[1 - i]]]]])
@@ -222,7 +239,7 @@ def test_mpc_planner_gt_mode(golden_dir):
     for i in range(2):
         pl = igtmpc.MPC_Planner(N=N, dt=0.1, ca_radius=2.8, agents=agents, routes=routes, ref=refs, goals=None,
                                 road_dim=(11.4, 50), ds_right=8.6, index=i, num_rk4_steps=4, dtype='f64',
-                                use_NN_cost2go=True, value_net=net)
+                                use_NN_cost2go=True, value_net=dict(net), cand_mode='lattice')
         pl.update_initial_condition(agents[i], inputs[i])
         pl.update_predictions(preds, raw_preds=preds)
         x, u, ok = pl.solve()
@@ -381,3 +398,86 @@ def test_value_net_solve_is_capturable_and_growth_under_capture_fails_loudly(gol
     for k in ('x', 'u', 'cost', 'argmin', 'status'):
         assert torch.equal(replayed[k].nan_to_num(), eager[k].nan_to_num()), k
     assert (eager['status'] == 0).float().mean() > 0.5
+
+
+def test_mpc_planner_warm_start_sequence_matches_oracle():
+    """The reference's per-step call sequence with the warm start (evaluate.py:470-482): solve, then
+    augment_prev_sol -> solve(x_sol_prev, u_sol_prev).  Default planner = ramp-hold candidates; with a warm start they are
+    centred on the shifted previous solution, which is then itself candidate (G/2, G/2)."""
+    import igtmpc
+    import closed_loop as CL
+    from igtmpc.planner import augment_prev_sol
+    routes, agents, refs = _scene()
+    N = 20
+    P = O.Params(N=N)
+    pred = igtmpc.ConstantAccelerationModel(N=N, dt=0.1)
+    inputs = [igtmpc.VehicleAction({'a': 0.1, 'df': 0.0}) for _ in routes]
+    preds = pred.predict(agents, inputs, routes, refs)
+    model = igtmpc.KinematicBicycleModelFrenet(2.235, 2.235, 2.0, 0.1, discretization='rk4', mode='numpy', num_rk4_steps=4)
+    i = 0
+    pl = igtmpc.MPC_Planner(N=N, dt=0.1, ca_radius=2.8, agents=agents, routes=routes, ref=refs, goals=None,
+                            road_dim=(11.4, 50), ds_right=8.6, index=i, num_rk4_steps=4)
+    assert pl.cand_mode == 'ramp_hold' and pl._solver.dtype == 'f64'
+    pl.update_initial_condition(agents[i], inputs[i])
+    pl.update_predictions(preds, raw_preds=preds)
+    x1, u1, ok = pl.solve()
+    assert ok
+    st = agents[i]['state']
+    x0 = np.array([st.state7()])
+    obs = np.array([[[[p.x for p in preds[1]], [p.y for p in preds[1]]]]])
+    kp = np.array([pl.K.kparams])
+    r1 = O.solve_batch_refined(x0, np.array([[0.1, 0.0]]), kp, np.array([0], np.uint32), obs, *pl.C_inf, P)[-1]
+    assert rel_err(x1, r1['x'][0]).max() < 1e-9 and rel_err(u1, r1['u'][0]).max() < 1e-12
+    # next step: state x1[:,1], applied input u1[:,0], warm start from augment_prev_sol
+    xw, uw = augment_prev_sol((x1, u1), model, st.K)
+    xo, uo = CL.augment_prev_sol(x1, u1, kp[0], P)
+    assert rel_err(xw, xo).max() < 1e-12 and np.array_equal(uw, uo)
+    nxt = dict(zip(('x', 'y', 's', 'ey', 'epsi', 'v', 'heading'), x1[:, 1]), K=st.K)
+    pl.update_initial_condition({'type': 'CAV', 'state': igtmpc.VehicleReference(nxt)}, igtmpc.VehicleAction({'a': u1[0, 0], 'df': u1[1, 0]}))
+    x2, u2, ok2 = pl.solve(x_sol_prev=xw, u_sol_prev=uw)
+    r2 = O.solve_batch_refined(x1[None, :, 1], u1[None, :, 0], kp, np.array([O.FLAG_WARM], np.uint32), obs, *pl.C_inf, P,
+                               u_ws=uw[None])[-1]
+    assert ok2 == (r2['status'][0] == 0)
+    if ok2:
+        assert rel_err(x2, r2['x'][0]).max() < 1e-9 and rel_err(u2, r2['u'][0]).max() < 1e-12
+        # the shifted previous plan is a candidate, so the new cost cannot exceed its cost
+        G = 16
+        cand = O.candidates_ramp_hold(u1[None, :, 0], np.zeros((1, 2)), np.array([[1.8, 1.4]]), True, P, 256, uw[None], np.array([True]))
+        assert rel_err(cand[0, (G // 2) * G + G // 2], uw).max() < 1e-12
+
+
+@pytest.mark.parametrize('cand_mode', ['lattice', 'ramp_hold'])
+def test_closed_loop_matches_oracle_loop(cand_mode):
+    """igtmpc.evaluate (batched, lock-step, GPU, float64 entry points) against oracle/closed_loop.py -- the plain
+    per-episode, per-agent restatement of evaluate.py:451-569: forecast -> share (v > 5 retry) -> filter -> warm start
+    -> solve -> brake fallback / instantaneous stop -> deadlock.  4 episodes x 30 steps; two sampled like the
+    reference samples them, one started fast (hits the shared-plan retry), one started outside the lane bound and slow
+    (hits the brake fallback and the v < 0 stop)."""
+    import closed_loop as CL
+    from igtmpc import routes as R
+    from igtmpc.cinf import cinf_halfplanes
+    from igtmpc.evaluate import initial_states, run_closed_loop
+    pairs = [R.SCENARIO_ROUTES[0][0], R.SCENARIO_ROUTES[3][1], ('13', '24'), ('13', '23')]
+    x, _ = initial_states(np.random.default_rng(2026), pairs)
+    x[0, :, 5] = 2.0                                              # sampled episodes start rolling (v0 = 0 crawls for 3 s)
+    x[1, :, 5] = 2.5
+    for m, (r, s0, v0) in enumerate(zip(pairs[2], (3.0, 5.0), (4.6, 4.7))):
+        xy = R.frenet2global(R.ROUTE_ID[r], s0)
+        x[2, m] = (xy[0], xy[1], s0, 0.0, 0.0, v0, float(R.psi_ref(R.ROUTE_ID[r], s0)))
+    x[3, 0, 3], x[3, 0, 5] = 0.25, 0.3                            # |ey_0| > 0.2: infeasible from the first step on
+    x[3, 1, 5] = 2.0
+    T = 3.0
+    got = run_closed_loop(N=20, T_sim=T, dtype='f64', cand_mode=cand_mode, init=(x, pairs))
+    P = O.Params(N=20)
+    cinf = cinf_halfplanes()
+    ev = dict(fallback=0, stop=0, share=0, share_retry=0, warm=0)
+    for e, pair in enumerate(pairs):
+        ref = CL.run_episode(x[e], pair, P, cinf, M_sim=30, cand_mode=cand_mode)
+        for k in ev:
+            ev[k] += ref['events'][k]
+        assert rel_err(got['x_data'][e], ref['x_data']).max() < 1e-9, (e, pair)
+        assert rel_err(got['u_data'][e], ref['u_data']).max() < 1e-9, (e, pair)
+        assert np.array_equal(got['infeasible_ratio'][e] * 30, ref['infeasible']), (e, pair)
+        assert bool(got['deadlock'][e]) == ref['deadlock']
+    assert ev['fallback'] > 0 and ev['stop'] > 0 and ev['share'] > 0 and ev['share_retry'] > 0
+    assert (ev['warm'] > 0) == (cand_mode == 'ramp_hold')

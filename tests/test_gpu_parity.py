@@ -520,3 +520,67 @@ def test_value_net_with_ramp_hold_refinement_f64(igt, golden_dir):
     assert sol.sum() > 10
     assert rel_err(got['x'][sol], ref['x'][sol]).max() < 1e-9
     assert rel_err(got['cost'][sol], ref['cost'][sol]).max() < 1e-9
+
+
+# ----------------------------------------------------------------------------- warm start (augment_prev_sol)
+@pytest.mark.parametrize('dtype,tol,eps', [('f64', 1e-9, 1e-9), ('f32', REL_TOL, 2e-5)])
+def test_warm_started_ramp_hold_matches_oracle(igt, dtype, tol, eps):
+    """igt_solve_batch_ws_* / igt_rollout_batch_ws_*: ramp-hold targets centred on a warm start (the previous solution
+    shifted by one step, utils.py:354-363) where flags carry IGT_FLAG_WARM, on u_prev held elsewhere; one refinement
+    pass on top.  Every candidate's controls and trajectory, then the solve."""
+    npdt = np.float64 if dtype == 'f64' else np.float32
+    B = 192
+    b = _batch(B, npdt)
+    f = lambda k: np.asarray(b[k], dtype=np.float64)
+    P0 = O.Params()
+    # a plausible previous solution per scenario: some lattice candidate rolled from u_prev, then shifted
+    prev = O.candidates_lattice(f('u_prev'), P0)[np.arange(B), (np.arange(B) * 37) % 256]       # [B,2,N]
+    u_ws = np.ascontiguousarray(O.shift_controls(prev).astype(npdt))
+    u_prev = np.ascontiguousarray(prev[:, :, 0].astype(npdt))                                     # the applied input
+    flags = b['flags'] | np.where(np.arange(B) % 3 != 0, 2, 0).astype(np.uint32)
+    args = (b['x0'], u_prev, b['kparams'], flags, b['obs_xy'])
+    with igt.BatchSolver(dtype=dtype, cand_mode='ramp_hold') as s0:
+        P = oracle_params(s0)
+        s0.set_cinf(*_cinf())
+        all0 = s0.rollout_all(*[a[:48] for a in args], u_ws=u_ws[:48])
+        first = s0.solve(*args, u_ws=u_ws)
+    with igt.BatchSolver(dtype=dtype, cand_mode='ramp_hold', refine_iters=1) as s1:
+        s1.set_cinf(*_cinf())
+        got = s1.solve(*args, u_ws=u_ws)
+    up = u_prev.astype(np.float64)
+    passes = O.solve_batch_refined(f('x0'), up, f('kparams'), flags, f('obs_xy'), *_cinf(), P, refine_iters=1,
+                                   u_ws=u_ws.astype(np.float64))
+    r0 = passes[0]
+    # the warm start itself is candidate (G/2, G/2) wherever the scenario carries one
+    w = (flags & 2) != 0
+    assert rel_err(r0['U'][w, 8 * 16 + 8], u_ws[w]).max() < 1e-7
+    assert not np.allclose(r0['U'][~w, 8 * 16 + 8], u_ws[~w])
+    assert rel_err(all0['U'], r0['U'][:48]).max() <= (0.0 if dtype == 'f64' else 1e-7)
+    kp = f('kparams')[:, None, :]
+    x0 = O.apply_flags(f('x0'), flags)[:, None, :]
+    bp = O.breakpoint_distance(x0, r0['U'], kp, P)
+    clear = bp[:48] > eps
+    err = rel_err(all0['X'], r0['X'][:48]).max(axis=(-1, -2))
+    assert err[clear].max() <= tol
+    amb0 = ambiguous_mask(r0, P, eps, eps, eps, bp)
+    ok0 = ~amb0
+    assert ok0.mean() > 0.85
+    assert (first['argmin'][ok0] == r0['argmin'][ok0]).all() and (first['status'][ok0] == r0['status'][ok0]).all()
+    sol = ok0 & (r0['status'] == 0)
+    assert sol.sum() > 30
+    assert rel_err(first['x'][sol], r0['x'][sol]).max() <= tol
+    assert rel_err(first['cost'][sol], r0['cost'][sol]).max() <= tol
+    # refined pass: costs agree wherever no threshold / break-point decided a pass inside float noise
+    edge = np.zeros(B, bool)
+    for r in passes:
+        edge |= ambiguous_mask(r, P, eps, eps, eps, O.breakpoint_distance(x0, r['U'], kp, P), ties=False)
+    ref = passes[-1]
+    tie = ~edge
+    assert tie.mean() > 0.8
+    assert (got['status'][tie] == ref['status'][tie]).all()
+    st = tie & (ref['status'] == 0)
+    assert rel_err(got['cost'][st], ref['cost'][st]).max() <= max(10 * tol, 1e-7)
+    # a warm start needs the ramp-hold family
+    with igt.BatchSolver(dtype=dtype) as s2:
+        with pytest.raises(igt.IgtError):
+            s2.solve(*args, u_ws=u_ws)

@@ -121,3 +121,30 @@ def test_nlp_quality_yardstick_runs():
     assert len(rows) >= 1
     assert (rows[:, 3] > -1e-6).all() and (rows[:, 3] < 1.5).all()
     assert np.allclose(rows[:, 1], sol['cost'][rows[:, 0].astype(int)], atol=1e-9)   # same cost function
+
+
+def test_oracle_closed_loop_and_warm_start_properties():
+    """oracle/closed_loop.py (restatement of evaluate.py:451-569): runs, exercises fallback / stop / sharing / warm
+    start, and the warm-started ramp-hold family contains the shifted previous plan."""
+    import closed_loop as CL
+    P = O.Params(N=10)
+    cinf = (None, None)
+    # straight crossing pair; agent 0 starts outside the lane bound and slow -> brake fallback, then the v < 0 stop
+    x = np.array([[3.0, 2.8 + 0.25, 3.0, 0.25, 0.0, 0.3, 0.0],
+                  [27.8, 40.0, 7.7 + 13.0, 0.0, 0.0, 3.0, -np.pi / 2]])
+    r = CL.run_episode(x, ('13', '24'), P, cinf, M_sim=6, cand_mode='ramp_hold', C=64)
+    ev = r['events']
+    assert ev['fallback'] >= 2 and ev['stop'] >= 1 and ev['share'] >= 4 and ev['warm'] >= 4
+    assert r['infeasible'][0] == 6 and r['infeasible'][1] == 0
+    assert r['x_data'][5, 1] < 0 and r['x_data'][5, 3] == 0.0          # braked below zero, then frozen at v = 0
+    assert np.all(np.diff(r['x_data'][7 + 2]) > 0)                      # the other agent keeps going
+    # the shifted previous plan is candidate (G/2, G/2) of the warm-started family
+    u_prev = np.array([[0.2, 0.01]])
+    prev = O.candidates_lattice(u_prev, P, 64)[0, 37]
+    ws = O.shift_controls(prev)
+    C, S = O.ramp_hold_first_params(prev[None, :, 0], P)
+    U = O.candidates_ramp_hold(prev[None, :, 0], C, S, True, P, 64, ws[None], np.array([True]))
+    assert np.abs(U[0, 4 * 8 + 4] - ws).max() < 1e-15
+    xa, ua = CL.augment_prev_sol(np.zeros((7, 11)) + np.array([0, 0, 0, 0, 0, 4.99, 0])[:, None], np.full((2, 10), 0.5),
+                                 np.array([np.inf, np.inf, 0.0]), P)
+    assert xa.shape == (7, 11) and ua.shape == (2, 10) and xa[5, -1] <= 5.0 and abs(xa[5, -1] - 4.99) < 1e-12   # a = 0 retry

@@ -5,8 +5,8 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 def family(name):
-    for key in ('search_fast', 'emit_fast', 'emit_seg', 'build_queues', 'value_mfma', 'value_compact', 'value_kernel', 'keys_to_partials', 'refine_targets',
-                'rollout_all', 'forecast', 'search_kernel', 'emit_kernel'):
+    for key in ('search_f64', 'emit_f64', 'search_fast', 'emit_fast', 'emit_seg', 'build_queues', 'value_mfma', 'value_compact', 'value_kernel',
+                'keys_to_partials', 'refine_targets', 'rollout_all', 'forecast', 'search_kernel', 'emit_kernel'):
         if key in name:
             return key
     return None
@@ -41,32 +41,50 @@ def main(root):
     c = out['counters_mean_per_launch']
     g = lambda k: c.get(k)
     B = int(os.environ.get('IGT_PMC_BATCH', '4096'))
+    dtype = os.environ.get('IGT_PMC_DTYPE', 'f64')
+    SF, EF = ('search_f64', 'emit_f64') if dtype == 'f64' else ('search_fast', 'emit_fast')
+    es = 8 if dtype == 'f64' else 4
+    units = (4 if dtype == 'f64' else 2) * B          # C = 256: 64-candidate units (f64) or 128-candidate units (f32)
     out['batch'] = B
+    out['dtype'] = dtype
+    out['search_kernel'] = SF
     # HBM bytes per launch, MI355X_MICROARCH.md HBM section: (FETCH_SIZE + WRITE_SIZE) * 1024, separate passes.  The
     # guide's x2 FETCH_SIZE correction is for 16 B/lane coalesced vector streams; the search kernel reads its inputs
     # with scalar (SMEM) loads, so the raw counter is reported.
-    for fam, key in (('search_fast', 'search'), ('emit_fast', 'emit')):
+    for fam, key in ((SF, 'search'), (EF, 'emit')):
         f, w = g(f'{fam}.FETCH_SIZE.pmc1'), g(f'{fam}.WRITE_SIZE.pmc2')
         if f is not None and w is not None:
             out[f'{key}_kernel_hbm_bytes_per_launch'] = (f + w) * 1024.0
-    out['algorithmic_bytes_per_launch'] = {'search': (220 + 12) * B, 'emit': 972 * B}
+    rd = (7 + 2 + 3 + 42) * es + 4                      # x0, u_prev, kparams, obs (x,y)[21], flags
+    out['algorithmic_bytes_per_launch'] = {'search': (rd + 12) * B, 'emit': (rd + (147 + 40) * es + es + 8) * B}
     d = {}
-    if g('search_fast.GRBM_GUI_ACTIVE.pmc4') and g('search_fast.dur_ns.pmc4'):
+    if g(f'{SF}.GRBM_GUI_ACTIVE.pmc4') and g(f'{SF}.dur_ns.pmc4'):
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs
-        d['shader_clock_GHz_during_search'] = g('search_fast.GRBM_GUI_ACTIVE.pmc4') / 8.0 / g('search_fast.dur_ns.pmc4')
-    if g('search_fast.SQ_WAVES.pmc3'):
-        waves = g('search_fast.SQ_WAVES.pmc3')
-        d['waves_per_launch'] = waves
-        d['valu_instructions_per_launch'] = g('search_fast.SQ_INSTS_VALU.pmc3')
-        d['valu_instructions_per_unit'] = g('search_fast.SQ_INSTS_VALU.pmc3') / (2.0 * B)
+        d['shader_clock_GHz_during_search'] = g(f'{SF}.GRBM_GUI_ACTIVE.pmc4') / 8.0 / g(f'{SF}.dur_ns.pmc4')
+    if g(f'{SF}.SQ_WAVES.pmc3'):
+        d['waves_per_launch'] = g(f'{SF}.SQ_WAVES.pmc3')
+        d['valu_instructions_per_launch'] = g(f'{SF}.SQ_INSTS_VALU.pmc3')
+        d['valu_instructions_per_unit'] = g(f'{SF}.SQ_INSTS_VALU.pmc3') / units
+        d['salu_instructions_per_launch'] = g(f'{SF}.SQ_INSTS_SALU.pmc3')
         clk = d.get('shader_clock_GHz_during_search', 2.23)
-        simd_cycles = 1024.0 * g('search_fast.dur_ns.pmc3') * clk
-        d['simd_valu_busy_fraction'] = 4.0 * g('search_fast.SQ_ACTIVE_INST_VALU.pmc3') / simd_cycles     # SQ_* are quad-cycles
-        d['mean_waves_resident_per_simd'] = 4.0 * g('search_fast.SQ_WAVE_CYCLES.pmc3') / simd_cycles
-        wc = g('search_fast.SQ_WAVE_CYCLES.pmc3')
-        d['wave_cycles_split'] = {'active': g('search_fast.SQ_ACTIVE_INST_ANY.pmc3') / wc,
-                                  'issue_stall': g('search_fast.SQ_WAIT_INST_ANY.pmc3') / wc}
+        simd_cycles = 1024.0 * g(f'{SF}.dur_ns.pmc3') * clk
+        d['simd_valu_busy_fraction'] = 4.0 * g(f'{SF}.SQ_ACTIVE_INST_VALU.pmc3') / simd_cycles     # SQ_* are quad-cycles
+        # instruction-based issue fraction: VALU wave-instructions x 4 issue cycles / (SIMDs x kernel cycles)
+        d['valu_issue_fraction_4_cycles_per_instruction'] = 4.0 * g(f'{SF}.SQ_INSTS_VALU.pmc3') / simd_cycles
+        d['mean_waves_resident_per_simd'] = 4.0 * g(f'{SF}.SQ_WAVE_CYCLES.pmc3') / simd_cycles
+        wc = g(f'{SF}.SQ_WAVE_CYCLES.pmc3')
+        d['wave_cycles_split'] = {'active': g(f'{SF}.SQ_ACTIVE_INST_ANY.pmc3') / wc,
+                                  'issue_stall': g(f'{SF}.SQ_WAIT_INST_ANY.pmc3') / wc}
     out['derived'] = d
+    # the kernel sources this profile belongs to (bench.py quotes PMC figures only at a matching hash)
+    import hashlib
+    hh = hashlib.sha256()
+    cs = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'igt-mpc-int_amd', 'csrc')
+    for fn in sorted(os.listdir(cs)):
+        if fn.endswith(('.hip', '.h', '.inc')):
+            with open(os.path.join(cs, fn), 'rb') as f:
+                hh.update(fn.encode() + b'\0' + f.read())
+    out['source_hash'] = hh.hexdigest()[:16]
     json.dump(out, sys.stdout, indent=1)
 
 if __name__ == '__main__':
