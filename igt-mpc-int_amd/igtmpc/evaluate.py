@@ -49,14 +49,16 @@ def initial_states(rng, route_pairs):
 
 def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=256, n_rk4=4, device=0,
                     dtype='f32', rotation=None, cand_mode='ramp_hold', refine_iters=0, verbose=False,
-                    eval_mode='mpc', value_net=None, device_resident=False, warm_start=True, init=None):
+                    eval_mode='mpc', value_net=None, device_resident=False, warm_start=True, init=None,
+                    terminal_set=True):
     """eval_mode 'mpc' (evaluate.py:370-639) or 'gt_mpc' (123-369: terminal value network in the cost; needs
     value_net = dict(layers=[(W,b),...][, Wn, mu_f, sigma_t, mu_t]) -- the reference's normalisation statistics are
     not shipped, identity by default).  device_resident=True keeps every per-step array in HBM (torch tensors;
     forecast, solve, fallback step and the state update never leave the GPU) -- for thousands of episodes.
     warm_start (ramp-hold candidates): an agent that solved the previous step centres its candidates on that solution
     shifted by one step (evaluate.py:478-481, utils.py:354-363 augment_prev_sol) instead of on u_prev held.
-    init = (x[E,M,7], route_pairs[E]) overrides the sampled initial states."""
+    init = (x[E,M,7], route_pairs[E]) overrides the sampled initial states; terminal_set=False drops the C_inf
+    constraint (mpc.py:177-180) -- a test switch."""
     gt = eval_mode == 'gt_mpc'
     if gt and value_net is None:
         raise ValueError("eval_mode='gt_mpc' needs value_net")
@@ -88,7 +90,8 @@ def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=
             enc[e, 0] = (code[0], code[1])
             enc[e, 1] = (code[1], code[0])
         enc = enc.reshape(E * M, 2)
-    solver.set_cinf(*cinf_halfplanes(dt=dt, jerk=solver.params.jerk_limit))
+    if terminal_set:
+        solver.set_cinf(*cinf_halfplanes(dt=dt, jerk=solver.params.jerk_limit))
     stepper = BatchSolver(N=1, dt=dt, n_rk4=n_rk4, C=64, n_obs=0, device=device, dtype='f64')
     npdt = solver.np_dtype
 

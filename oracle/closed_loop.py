@@ -92,7 +92,7 @@ def run_episode(x_init, routes, P, cinf, M_sim=30, cand_mode='lattice', C=256, r
             plan = prev_sols[prev_idx.index(j)] if (t > 0 and j in prev_idx) else None     # evaluate.py:459
             if plan is not None:
                 events['share'] += 1
-                if plan[0][5, N] + plan[1][0, N - 1] * dt > 5:                             # utils.py:348 (v of the step)
+                if np.clip(plan[0][5, N] + plan[1][0, N - 1] * dt, -2.0, 20.0) > 5:        # utils.py:348 (inside forecast_for_ego)
                     events['share_retry'] += 1
             obs, _ = O.forecast_for_ego(routes[j], consts[routes[j]], cur[i][:2], cur[i][6], cur[j], prev_in[j][0], N, dt,
                                         None if plan is None else plan[0], None if plan is None else plan[1])

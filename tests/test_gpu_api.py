@@ -466,18 +466,24 @@ def test_closed_loop_matches_oracle_loop(cand_mode):
         x[2, m] = (xy[0], xy[1], s0, 0.0, 0.0, v0, float(R.psi_ref(R.ROUTE_ID[r], s0)))
     x[3, 0, 3], x[3, 0, 5] = 0.25, 0.3                            # |ey_0| > 0.2: infeasible from the first step on
     x[3, 1, 5] = 2.0
-    T = 3.0
-    got = run_closed_loop(N=20, T_sim=T, dtype='f64', cand_mode=cand_mode, init=(x, pairs))
     P = O.Params(N=20)
-    cinf = cinf_halfplanes()
     ev = dict(fallback=0, stop=0, share=0, share_retry=0, warm=0)
-    for e, pair in enumerate(pairs):
-        ref = CL.run_episode(x[e], pair, P, cinf, M_sim=30, cand_mode=cand_mode)
-        for k in ev:
-            ev[k] += ref['events'][k]
-        assert rel_err(got['x_data'][e], ref['x_data']).max() < 1e-9, (e, pair)
-        assert rel_err(got['u_data'][e], ref['u_data']).max() < 1e-9, (e, pair)
-        assert np.array_equal(got['infeasible_ratio'][e] * 30, ref['infeasible']), (e, pair)
-        assert bool(got['deadlock'][e]) == ref['deadlock']
-    assert ev['fallback'] > 0 and ev['stop'] > 0 and ev['share'] > 0 and ev['share_retry'] > 0
+    # With the terminal set, a feasible plan ends inside C_inf, i.e. at most 0.009 m/s above v = 5 one step later: the
+    # shared-plan retry (utils.py:348) is all but unreachable.  The fast episode therefore runs without it.
+    for sel, terminal in (([0, 1, 3], True), ([2], False)):
+        got = run_closed_loop(N=20, T_sim=3.0, dtype='f64', cand_mode=cand_mode, init=(x[sel], [pairs[e] for e in sel]),
+                              terminal_set=terminal)
+        cinf = cinf_halfplanes() if terminal else (None, None)
+        for q, e in enumerate(sel):
+            ref = CL.run_episode(x[e], pairs[e], P, cinf, M_sim=30, cand_mode=cand_mode)
+            for k in ev:
+                ev[k] += ref['events'][k]
+            assert rel_err(got['x_data'][q], ref['x_data']).max() < 1e-9, (e, pairs[e])
+            assert rel_err(got['u_data'][q], ref['u_data']).max() < 1e-9, (e, pairs[e])
+            assert np.array_equal(got['infeasible_ratio'][q] * 30, ref['infeasible']), (e, pairs[e])
+            assert bool(got['deadlock'][q]) == ref['deadlock']
+    assert ev['fallback'] > 0 and ev['stop'] > 0 and ev['share'] > 0, ev
+    # constant-increment lattice plans started at a = 0.1 never end above v = 5 one step past the horizon; ramp-hold
+    # plans do (the retry branch itself is also pinned directly in test_forecast_matches_oracle)
+    assert (ev['share_retry'] > 0) == (cand_mode == 'ramp_hold'), ev
     assert (ev['warm'] > 0) == (cand_mode == 'ramp_hold')
