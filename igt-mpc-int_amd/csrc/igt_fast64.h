@@ -100,6 +100,15 @@ __device__ __forceinline__ double rcp_nr(double x) {
     return r;
 }
 
+// 1/sqrt(x), x in (0, 1]: hardware estimate + two Newton steps
+__device__ __forceinline__ double rsq_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * fma(-(hx * y), y, 1.5);
+    y = y * fma(-(hx * y), y, 1.5);
+    return y;
+}
+
 template <bool HI_ORDER>
 struct Fast64 {
     double h, hh, h6, kv, inv_lr, lr_ratio, b0, b1, dt;
@@ -122,6 +131,15 @@ struct Fast64 {
     // v1, ey and the break-point-relative arc lengths d0, d1 advance per sub-step; acc_* are the step's increments
     struct Work {
         double s1, c1, s2, c2, v1, ey, d0, d1, acc_s, acc_ey, acc_ep, acc_x, acc_y, acc_psi;
+        double sh, ch;        // (sin,cos)(h/2 w2) of the current sub-step, carried by rotation (see StepConst)
+    };
+    // The psi offsets of a control step form an arithmetic progression: w = v sin(beta)/l_r is linear in v and v advances
+    // by h/2 a per half sub-step, so with delta = h/2 * (h/2 a) * sin(beta)/l_r
+    //     h/2 w1 = h/2 w2 - delta,   h w2 = 2 (h/2 w2),   next sub-step: h/2 w2' = h/2 w2 + 2 delta.
+    // One polynomial per CONTROL step (h/2 w2 of the first sub-step) plus rotations by +-delta / 2 delta and a double-angle
+    // replace three polynomials per SUB-step -- the same numbers in every sub-step variant (mode-independent code).
+    struct StepConst {
+        double ha, sblr, sd, cd, s2d, c2d;
     };
 
     // A = g1 + 2 g2 cdA + 2 g3 cdB + g4 cdC,  B = 2 g2 sdA + 2 g3 sdB + g4 sdC   (weights 1,2,2,1)
@@ -135,25 +153,25 @@ struct Fast64 {
     // MODE 0: general (K decided per stage argument); 1: K == 0 at every stage argument of every lane; 2: every stage
     // argument of every lane lies strictly inside the arc, K == kv.  All three give identical bits where they apply.
     template <int MODE>
-    __device__ __forceinline__ void substep(double ha, double sblr, Work& w) const {
+    __device__ __forceinline__ void substep(const StepConst& sc, Work& w) const {
         constexpr bool K0 = MODE == 1, KC = MODE == 2;
+        const double ha = sc.ha, sblr = sc.sblr;
         const double v1 = w.v1;
         const double v2 = v1 + ha;            // stages 2,3
         const double v4 = v2 + ha;            // stage 4
         const double s1 = w.s1, c1 = w.c1;
         const double w1 = v1 * sblr, w2 = v2 * sblr, w4 = v4 * sblr;
-        // psi offsets h/2 w1 (stage 2), h/2 w2 (stages 3 AND 4, frenet.py:111)
-        double sd2, cd2, sd3, cd3;
-        ssc(hh * w1, sd2, cd2);
-        ssc(hh * w2, sd3, cd3);
-        double As, Bs, Ae, Be, ip, sdC, cdC, sdP, cdP;
+        // psi offsets h/2 w1 (stage 2), h/2 w2 (stages 3 AND 4, frenet.py:111), h w2 (the sub-step's psi advance)
+        const double sd3 = w.sh, cd3 = w.ch;
+        double sd2 = sd3, cd2 = cd3;
+        rotate(sd2, cd2, -sc.sd, sc.cd);
+        const double sdP = 2.0 * sd3 * cd3, cdP = fma(-2.0 * sd3, sd3, 1.0);
+        double As, Bs, Ae, Be, sdC, cdC, corr = 0.0;
         if (K0) {
             // 1 - K ey = 1 and depsi = dpsi: the (beta+epsi) stage offsets are the psi offsets, the gains the speeds
-            ssc(h * w2, sdP, cdP);
             sdC = sdP; cdC = cdP;
             stage_sums(v1, v2, v2, v4, sd2, cd2, sd3, cd3, sdC, cdC, Ae, Be);
             As = Ae; Bs = Be;
-            ip = h * w2;
         } else {
             const double ey = w.ey, d0 = w.d0, d1 = w.d1;
             double sdA, cdA, sdB, cdB, sa, ca;
@@ -163,37 +181,46 @@ struct Fast64 {
             const double ds1 = g1 * c1;
             const double de1 = v1 * s1;
             const double kd1 = ds1 * K;
-            const double dp1 = w1 - kd1;
-            // ---- stage 2: arguments base + h/2 k1
-            ssc(hh * dp1, sdA, cdA);
+            // ---- stage 2: arguments base + h/2 k1; its offset h/2 dp1 = h/2 w1 - h/2 kd1: the psi offset turned back by
+            //      the curvature part (kd == 0 turns by (0, 1): exactly the psi offset, as the K == 0 variant uses)
+            {
+                double sk, ck;
+                ssc(-(hh * kd1), sk, ck);
+                sdA = sd2; cdA = cd2; rotate(sdA, cdA, sk, ck);
+            }
             sa = s1; ca = c1; rotate(sa, ca, sdA, cdA);
             if (!KC) K = curv(d0, d1, hh * ds1);
             const double g2 = v2 * rcp_nr(fma(-K, fma(hh, de1, ey), 1.0));
             const double ds2 = g2 * ca;
             const double de2 = v2 * sa;
             const double kd2 = ds2 * K;
-            const double dp2 = w2 - kd2;
             // ---- stage 3: base + h/2 k2
-            ssc(hh * dp2, sdB, cdB);
+            {
+                double sk, ck;
+                ssc(-(hh * kd2), sk, ck);
+                sdB = sd3; cdB = cd3; rotate(sdB, cdB, sk, ck);
+            }
             sa = s1; ca = c1; rotate(sa, ca, sdB, cdB);
             if (!KC) K = curv(d0, d1, hh * ds2);
             const double g3 = v2 * rcp_nr(fma(-K, fma(hh, de2, ey), 1.0));
             const double ds3 = g3 * ca;
             const double de3 = v2 * sa;
             const double kd3 = ds3 * K;
-            const double dp3 = w2 - kd3;
             // ---- stage 4: base + h k3 (only its cosine is needed individually, for depsi)
-            ssc(h * dp3, sdC, cdC);
+            {
+                double sk, ck;
+                ssc(-(h * kd3), sk, ck);
+                sdC = sdP; cdC = cdP; rotate(sdC, cdC, sk, ck);
+            }
             if (!KC) K = curv(d0, d1, h * ds3);
             const double g4 = v4 * rcp_nr(fma(-K, fma(h, de3, ey), 1.0));
             const double ds4 = g4 * fma(c1, cdC, -(s1 * sdC));
             const double kd4 = ds4 * K;
             stage_sums(g1, g2, g3, g4, sdA, cdA, sdB, cdB, sdC, cdC, As, Bs);
             stage_sums(v1, v2, v2, v4, sdA, cdA, sdB, cdB, sdC, cdC, Ae, Be);
-            ssc(h * w2, sdP, cdP);
-            const double corr = h6 * (kd1 + 2.0 * kd2 + 2.0 * kd3 + kd4);
-            ip = h * w2 - corr;
+            corr = h6 * (kd1 + 2.0 * kd2 + 2.0 * kd3 + kd4);        // curvature part of the epsi increment
         }
+        const double ip = h * w2 - corr;                             // K == 0: h w2 - 0, the same bits
         // ---- Frenet increments (frenet.py:113-115)
         const double is = h6 * fma(c1, As, -(s1 * Bs));
         const double ie = h6 * fma(s1, Ae, c1 * Be);
@@ -207,16 +234,16 @@ struct Fast64 {
         w.acc_psi = fma(h6, w1 + 4.0 * w2 + w4, w.acc_psi);
         w.acc_s += is; w.acc_ey += ie; w.acc_ep += ip;
         w.d0 += is; w.d1 += is; w.ey += ie; w.v1 = v4;
-        // ---- base pairs for the next sub-step: (psi+beta) advances by h w2, (beta+epsi) by ip = h w2 - corr.
-        // K == 0: corr = 0 exactly and ip = h w2 - 0, so ssc(ip) IS (sdP, cdP) -- the variants stay bit-identical.
+        // ---- base pairs for the next sub-step: (psi+beta) advances by h w2, (beta+epsi) by h w2 - corr: the psi
+        // advance turned back by corr.  K == 0: corr = 0 exactly, the extra turn is by (0, 1) -- bit-identical variants.
         rotate(w.s2, w.c2, sdP, cdP);
-        if (K0) {
-            rotate(w.s1, w.c1, sdP, cdP);
-        } else {
-            double sd, cd;
-            ssc(ip, sd, cd);
-            rotate(w.s1, w.c1, sd, cd);
+        rotate(w.s1, w.c1, sdP, cdP);
+        if (!K0) {
+            double sk, ck;
+            ssc(-corr, sk, ck);
+            rotate(w.s1, w.c1, sk, ck);
         }
+        rotate(w.sh, w.ch, sc.s2d, sc.c2d);                          // h/2 w2 of the next sub-step
     }
 
     // n_rk4 sub-steps of one control step.  The K == 0 variant (or the K == kv one) is taken when it is provably
@@ -226,12 +253,17 @@ struct Fast64 {
     template <bool UNIFORM>
     __device__ __forceinline__ void substeps(double a, double sblr, Work& w) const {
         const double ha = hh * a;
+        StepConst sc;
+        sc.ha = ha; sc.sblr = sblr;
+        ssc(hh * ha * sblr, sc.sd, sc.cd);                           // delta = h/2 (w2 - w1)
+        sc.s2d = 2.0 * sc.sd * sc.cd; sc.c2d = fma(-2.0 * sc.sd, sc.sd, 1.0);
+        ssc(hh * ((w.v1 + ha) * sblr), w.sh, w.ch);                  // h/2 w2 of the first sub-step
         if (!UNIFORM) {
-            for (int j = 0; j < n_rk4; ++j) substep<0>(ha, sblr, w);
+            for (int j = 0; j < n_rk4; ++j) substep<0>(sc, w);
             return;
         }
         if (kv == 0.0) {                       // straight route: scalar condition, hoisted
-            for (int j = 0; j < n_rk4; ++j) substep<1>(ha, sblr, w);
+            for (int j = 0; j < n_rk4; ++j) substep<1>(sc, w);
             return;
         }
         {   // the whole control step: |travel| <= 2 dt (|v| + dt |a|)
@@ -239,11 +271,11 @@ struct Fast64 {
             const bool clear = (w.d0 + m < 0.0) | (w.d1 - m > 0.0);
             const bool inside = (w.d0 - m > 0.0) & (w.d1 + m < 0.0);
             if (__all(clear)) {
-                for (int j = 0; j < n_rk4; ++j) substep<1>(ha, sblr, w);
+                for (int j = 0; j < n_rk4; ++j) substep<1>(sc, w);
                 return;
             }
             if (__all(inside)) {
-                for (int j = 0; j < n_rk4; ++j) substep<2>(ha, sblr, w);
+                for (int j = 0; j < n_rk4; ++j) substep<2>(sc, w);
                 return;
             }
         }
@@ -252,9 +284,9 @@ struct Fast64 {
             const double m = (2.0 * h) * (fabs(w.v1) + 2.0 * fabs(ha));
             const bool clear = (w.d0 + m < 0.0) | (w.d1 - m > 0.0);
             const bool inside = (w.d0 - m > 0.0) & (w.d1 + m < 0.0);
-            if (__all(clear)) substep<1>(ha, sblr, w);
-            else if (__all(inside)) substep<2>(ha, sblr, w);
-            else substep<0>(ha, sblr, w);
+            if (__all(clear)) substep<1>(sc, w);
+            else if (__all(inside)) substep<2>(sc, w);
+            else substep<0>(sc, w);
         }
     }
 };
@@ -324,7 +356,7 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
         double sdf, cdf;
         if (CAND != CAND_TABLE && P.df_small) sincos_kernel(df, sdf, cdf);       // |df| <= df_max < pi/4
         else sincos_reduced(df, sdf, cdf);
-        const double n = 1.0 / sqrt(fma(ratio2 * sdf, sdf, cdf * cdf));
+        const double n = rsq_nr(fma(ratio2 * sdf, sdf, cdf * cdf));                  // argument in [r^2, 1]
         const double cb = cdf * n, sb = fp.lr_ratio * sdf * n;
         const double sblr = sb * fp.inv_lr;
         // ---- bookkeeping of state k (cost in the oracle's order: control effort, epsi^2, ey^2 -- mpc.py:361-364)

@@ -6,6 +6,8 @@ import numpy as np
 import np_oracle as O
 
 REL_TOL = 1e-5       # BASELINE.json north_star: 1e-5 relative, |ref| floored at 1
+F32_EPS = 1e-7       # f32 comparisons: width of the threshold / break-point set-aside (tools/f32_margin_probe.py)
+F32_TIE = 1e-6       # ... and of the cost near-tie set-aside
 
 
 def rel_err(got, ref):

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 import np_oracle as O
-from helpers import REL_TOL, ambiguous_mask, oracle_params, rel_err
+from helpers import F32_EPS, F32_TIE, REL_TOL, ambiguous_mask, oracle_params, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -54,9 +54,12 @@ def _check_subsample(b, got, idx, P, tol, eps, net=None):
     kp = f('kparams')[:, None, :]
     x0 = O.apply_flags(f('x0'), b['flags'][idx])[:, None, :]
     bp = O.breakpoint_distance(x0, ref['U'], kp, P)
-    amb = ambiguous_mask(ref, P, eps, eps, eps, bp)
+    # cost near-ties: 1e-6 for the f32 rollout arithmetic; the f32 value network (MFMA, hardware exp/rcp tanh) adds
+    # ~1e-6 relative error to V, so with the terminal value in the cost ties are set aside at 2e-5
+    tie = eps if eps != F32_EPS else (2e-5 if net is not None else F32_TIE)
+    amb = ambiguous_mask(ref, P, eps, tie, eps, bp)
     ok = ~amb
-    assert ok.mean() > 0.9, f'only {ok.mean():.3f} of the subsample is decided outside float noise'
+    assert ok.mean() > 0.99, f'only {ok.mean():.3f} of the subsample is decided outside float noise'
     g = {k: got[k][idx] for k in ('x', 'u', 'cost', 'argmin', 'status')}
     assert (g['status'][ok] == ref['status'][ok]).all()
     assert (g['argmin'][ok] == ref['argmin'][ok]).all()
@@ -101,20 +104,20 @@ def _run(igt, B, offset, dtype, tol, eps, golden_dir=None, gt_sc=0):
     print(f'B={B} dtype={dtype} gt={gt_sc}: ambiguous share of the subsample {amb:.4f}')
 
 
-@pytest.mark.parametrize('dtype,tol,eps', [('f64', 1e-9, 1e-9), ('f32', REL_TOL, 2e-5)])
+@pytest.mark.parametrize('dtype,tol,eps', [('f64', 1e-9, 1e-9), ('f32', REL_TOL, F32_EPS)])
 def test_config2_batch_65536(igt, dtype, tol, eps):
     """BASELINE configs[2]: batch = 65 536, all 8 sc variants tiled, horizon 20, Frenet-frame model."""
     _run(igt, 65536, 0, dtype, tol, eps)
 
 
-@pytest.mark.parametrize('dtype,tol,eps', [('f64', 1e-9, 1e-9), ('f32', REL_TOL, 2e-5)])
+@pytest.mark.parametrize('dtype,tol,eps', [('f64', 1e-9, 1e-9), ('f32', REL_TOL, F32_EPS)])
 def test_config3_shard_32768(igt, dtype, tol, eps):
     """BASELINE configs[3]: 262 144 scenarios sharded 8 ways = 32 768 per GPU; rank 3's shard (offset 3 x 32 768,
     the generator's per-rank offset path).  The all-gather across ranks is covered by tests/test_sharding_gloo.py."""
     _run(igt, 32768, 3 * 32768, dtype, tol, eps)
 
 
-@pytest.mark.parametrize('dtype,tol,eps,sc', [('f64', 1e-9, 1e-9, 1), ('f32', REL_TOL, 2e-5, 1), ('f32', REL_TOL, 2e-5, 3)])
+@pytest.mark.parametrize('dtype,tol,eps,sc', [('f64', 1e-9, 1e-9, 1), ('f32', REL_TOL, F32_EPS, 1), ('f32', REL_TOL, F32_EPS, 3)])
 def test_config4_gt_mpc_65536(igt, golden_dir, dtype, tol, eps, sc):
     """BASELINE configs[4]: gt_mpc, terminal value network (shipped V_GT_sc1: 2 hidden layers, V_GT_sc3: 3) evaluated
     on the GPU inside the cost, batch = 65 536 (per GPU; the 8-GPU run itself is the driver's)."""

@@ -4,6 +4,11 @@ Bars:
   f64 entry points : 1e-9 * max(1,|ref|)   (same operation order as the oracle; only libm differs)
   f32 entry points : 1e-5 * max(1,|ref|)   (BASELINE.json north_star), arg-min / status exact
                      on every scenario that is not decided inside float32 noise.
+Set-asides of the f32 comparisons (tools/f32_margin_probe.py measured them on 2048 scenarios / 65 536 rollouts:
+the f32 entry agreed with the oracle on EVERY arg-min with no set-aside at all, and every rollout -- including those
+with a stage argument within 1e-7 m of a curvature break-point -- stayed below 2.7e-6): a contender within F32_EPS = 1e-7
+of a constraint threshold or of a break-point, or two best costs closer than F32_TIE = 1e-6.  The excluded share is
+asserted (< 0.5 %) and printed.
 """
 import os
 
@@ -11,7 +16,7 @@ import numpy as np
 import pytest
 
 import np_oracle as O
-from helpers import REL_TOL, ambiguous_mask, oracle_params, oracle_solve, rel_err
+from helpers import F32_EPS, F32_TIE, REL_TOL, ambiguous_mask, oracle_params, oracle_solve, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -68,20 +73,21 @@ def test_rollout_all_f32_within_1e5(igt):
     x0 = O.apply_flags(b['x0'].astype(np.float64), b['flags'])[:, None, :]
     bp = O.breakpoint_distance(x0, ref['U'], kp, P)
     err = rel_err(got['X'], ref['X']).max(axis=(-1, -2))
-    clear = bp > 2e-5
-    assert clear.mean() > 0.98, 'too many break-point-sensitive rollouts in the sample'
+    clear = bp > F32_EPS
+    print(f'rollouts set aside (stage argument within {F32_EPS:g} m of a break-point): {(~clear).mean():.5f}')
+    assert clear.mean() > 0.999, 'too many break-point-sensitive rollouts in the sample'
     assert err[clear].max() <= REL_TOL, f'max rel err {err[clear].max():.3e}'
     # a curvature switch decided inside float32 noise moves a trajectory by O(1e-3) at most
     assert err.max() < 5e-2
     cerr = rel_err(got['cost'], ref['J'])
     assert cerr[clear].max() <= REL_TOL
-    thr = np.abs(ref['g'] - P.feas_tol) > 2e-5
+    thr = np.abs(ref['g'] - P.feas_tol) > 1e-6       # verdicts are formed in float from the double state
     assert ((got['viol'] == 0) == ref['feas'])[clear & thr].all()
 
 
 # ----------------------------------------------------------------------------- solves
-@pytest.mark.parametrize('dtype,tol,eps', [('f64', 1e-9, 1e-9), ('f32', REL_TOL, 2e-5)])
-def test_solve_matches_oracle(igt, dtype, tol, eps):
+@pytest.mark.parametrize('dtype,tol,eps,eps_tie', [('f64', 1e-9, 1e-9, 1e-9), ('f32', REL_TOL, F32_EPS, F32_TIE)])
+def test_solve_matches_oracle(igt, dtype, tol, eps, eps_tie):
     npdt = np.float64 if dtype == 'f64' else np.float32
     b = _batch(512, npdt)
     with igt.BatchSolver(dtype=dtype) as s:
@@ -92,8 +98,9 @@ def test_solve_matches_oracle(igt, dtype, tol, eps):
     kp = b['kparams'].astype(np.float64)[:, None, :]
     x0 = O.apply_flags(b['x0'].astype(np.float64), b['flags'])[:, None, :]
     bp = O.breakpoint_distance(x0, ref['U'], kp, P)
-    amb = ambiguous_mask(ref, P, eps, eps, eps, bp)
-    assert amb.mean() < 0.10
+    amb = ambiguous_mask(ref, P, eps, eps_tie, eps, bp)
+    print(f'{dtype}: scenarios set aside (threshold / break-point within {eps:g}, tie within {eps_tie:g}): {amb.sum()} of {len(amb)}')
+    assert amb.mean() < 0.005
     ok = ~amb
     assert (got['status'][ok] == ref['status'][ok]).all()
     assert (got['argmin'][ok] == ref['argmin'][ok]).all()
@@ -107,8 +114,8 @@ def test_solve_matches_oracle(igt, dtype, tol, eps):
         c = got['argmin'][i]
         if c >= 0:
             best = np.where(ref['feas'][i], ref['J'][i], np.inf).min()
-            assert ref['g'][i, c] <= P.feas_tol + 10 * eps
-            assert ref['J'][i, c] <= best + 10 * eps or not np.isfinite(best)
+            assert ref['g'][i, c] <= P.feas_tol + 10 * eps_tie
+            assert ref['J'][i, c] <= best + 10 * eps_tie or not np.isfinite(best)
     # status-1 rows carry NaN / inf / -1
     bad = got['status'] == 1
     if bad.any():
@@ -198,7 +205,7 @@ def test_golden_frenet_rollouts_table_mode(igt, golden_dir):
                     ref = O.rollout_frenet(x0.astype(np.float64), U, kp.astype(np.float64), P)
                     bp = O.breakpoint_distance(x0.astype(np.float64), U, kp.astype(np.float64), P)
                 e = rel_err(got, ref).max(axis=(-1, -2))
-                worst = max(worst, e[bp > 2e-5].max())
+                worst = max(worst, e[bp > F32_EPS].max())
         assert worst <= tol, f'{dtype}: {worst:.3e}'
 
 
@@ -349,7 +356,7 @@ def test_full_size_properties(igt):
     X = O.rollout_frenet(x0, base['u'][idx].astype(np.float64), b['kparams'][idx].astype(np.float64), P)
     bp = O.breakpoint_distance(x0, base['u'][idx].astype(np.float64), b['kparams'][idx].astype(np.float64), P)
     e = rel_err(base['x'][idx], X).max(axis=(-1, -2))
-    assert e[bp > 2e-5].max() <= REL_TOL
+    assert e[bp > F32_EPS].max() <= REL_TOL
 
 
 # ----------------------------------------------------------------------------- value network (gt_mpc, config 5)
@@ -461,7 +468,7 @@ def test_ramp_hold_with_refinement_matches_oracle(igt, dtype, tol, eps):
     X = O.rollout_frenet(x0[st, 0], got['u'][st].astype(np.float64), kp[st, 0], P)
     bpu = O.breakpoint_distance(x0[st, 0], got['u'][st].astype(np.float64), kp[st, 0], P)
     e = rel_err(got['x'][st], X).max(axis=(-1, -2))
-    assert e[bpu > 2e-5].max() <= tol
+    assert e[bpu > F32_EPS].max() <= tol
     # refinement never makes the answer worse, and improves it somewhere
     both = (passes[0]['status'] == 0) & (ref['status'] == 0)
     assert (ref['cost'][both] <= passes[0]['cost'][both] + 1e-12).all()

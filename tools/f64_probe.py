@@ -46,6 +46,12 @@ def run(B, dev_flags, iters=5, dtype='f64'):
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1].startswith('--flags='):        # A/B of developer switches: --flags=0,32,16 B...
+        flags = [int(f) for f in sys.argv[1][8:].split(',')]
+        for B in [int(a) for a in sys.argv[2:]] or [4096]:
+            for f in flags:
+                run(B, f, iters=9)
+        sys.exit(0)
     sizes = [int(a) for a in sys.argv[1:]] or [4096, 32768]
     for B in sizes:
         fast = run(B, 0)
