@@ -2,6 +2,8 @@
 // validation, host staging, launches).  No exceptions cross the boundary.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -53,9 +55,48 @@ struct igt_handle {
     bool ev_recorded;
     int nc;
     int n_cu;              // compute units of the device (sizes the persistent search grid)
+    void* comm;            // RCCL communicator of igt_comm_init (null: none)
+    int comm_world, comm_rank;
+    void* d_u0;            // [B_local,2] first-step controls staged for the all-gather
+    size_t u0_bytes;
 };
 
 namespace {
+
+// RCCL is bound at run time (dlopen), not at link time: a single-GPU user needs no RCCL at all, and a process that
+// already carries one (torch ships its own librccl.so.1) must not get a second copy.
+struct IgtNcclId { char internal[IGT_COMM_ID_BYTES]; };
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(IgtNcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, IgtNcclId, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl* rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names)
+            if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;          // one the process already mapped
+        for (int i = 0; !r.lib && i < 3; ++i) r.lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        if (r.lib) {
+            r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+            r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+            r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
+            r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+            r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+            if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) r.lib = nullptr;
+        }
+    }
+    return r.lib ? &r : nullptr;
+}
+int rccl_fail(Rccl* r, const char* what, int rc) {
+    return fail(IGT_E_HIP, std::string(what) + ": " + (r && r->GetErrorString ? r->GetErrorString(rc) : "RCCL error"));
+}
 
 int isqrt_exact(int c) {
     int g = (int)std::lround(std::sqrt((double)c));
@@ -519,6 +560,36 @@ int cartesian_impl(igt_handle* h, int32_t n, int32_t steps, const T* z0, const T
     return IGT_OK;
 }
 
+template <typename T>
+int allgather_impl(igt_handle* h, int32_t B_local, const T* u_out, T* u0_all, void* stream) {
+    if (!h) return fail(IGT_E_INVALID, "null handle");
+    if (B_local < 0) return fail(IGT_E_INVALID, "B_local < 0");
+    if (B_local == 0) return IGT_OK;
+    if (!u_out || !u0_all) return fail(IGT_E_INVALID, "null buffer");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const int world = h->comm ? h->comm_world : 1, rank = h->comm ? h->comm_rank : 0;
+    if (world == 1) {       // one shard: the gathered vector is the local one
+        HIPCHK(igt::launch_first_controls<T>(B_local, h->p.N, u_out, u0_all, st));
+        return IGT_OK;
+    }
+    (void)rank;
+    const size_t bytes = (size_t)B_local * 2 * sizeof(T);
+    if (bytes > h->u0_bytes) {
+        if (capturing(st)) return fail(IGT_E_STATE, "staging buffer too small for stream capture: run one eager call first");
+        HIPCHK(hipStreamSynchronize(st));
+        if (h->d_u0) { HIPCHK(hipFree(h->d_u0)); h->d_u0 = nullptr; h->u0_bytes = 0; }
+        HIPCHK(hipMalloc(&h->d_u0, bytes + 256));
+        h->u0_bytes = bytes;
+    }
+    HIPCHK(igt::launch_first_controls<T>(B_local, h->p.N, u_out, reinterpret_cast<T*>(h->d_u0), st));
+    Rccl* r = rccl();
+    if (int rc = r->AllGather(h->d_u0, u0_all, (size_t)B_local * 2, sizeof(T) == 4 ? 7 /* ncclFloat */ : 8 /* ncclDouble */,
+                              h->comm, st))
+        return rccl_fail(r, "ncclAllGather", rc);
+    return IGT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -563,6 +634,7 @@ int igt_create(const igt_params* p, int device, igt_handle** out) {
     h->d_net = nullptr;
     h->d_routes = nullptr; h->n_routes = 0;
     h->prof = false; h->ev_recorded = false;
+    h->comm = nullptr; h->comm_world = 1; h->comm_rank = 0; h->d_u0 = nullptr; h->u0_bytes = 0;
     h->nc = 2;
     if (const char* e = std::getenv("IGT_NC")) {
         const int v = std::atoi(e);
@@ -591,6 +663,8 @@ int igt_destroy(igt_handle* h) {
     if (h->d_work) (void)hipFree(h->d_work);
     if (h->d_net) (void)hipFree(h->d_net);
     if (h->d_routes) (void)hipFree(h->d_routes);
+    if (h->d_u0) (void)hipFree(h->d_u0);
+    if (h->comm) { if (Rccl* r = rccl()) (void)r->CommDestroy(h->comm); }
     for (int i = 0; i < 3; ++i) (void)hipEventDestroy(h->ev[i]);
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -830,6 +904,49 @@ int igt_cartesian_euler_f32(igt_handle* h, int32_t n, int32_t T, const float* z0
 int igt_cartesian_euler_f64(igt_handle* h, int32_t n, int32_t T, const double* z0, const double* u, double* z_out,
                             int mem, void* stream) {
     return cartesian_impl<double>(h, n, T, z0, u, z_out, mem, stream);
+}
+
+int igt_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(IGT_E_INVALID, "null argument");
+    Rccl* r = rccl();
+    if (!r) return fail(IGT_E_STATE, "RCCL (librccl.so.1) could not be loaded");
+    IgtNcclId id;
+    if (int rc = r->GetUniqueId(&id)) return rccl_fail(r, "ncclGetUniqueId", rc);
+    std::memcpy(id_out, id.internal, IGT_COMM_ID_BYTES);
+    return IGT_OK;
+}
+
+int igt_comm_init(igt_handle* h, int32_t world, int32_t rank, const void* id) {
+    if (!h || !id) return fail(IGT_E_INVALID, "null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(IGT_E_INVALID, "need 0 <= rank < world");
+    if (h->comm) return fail(IGT_E_STATE, "communicator already initialised (igt_comm_destroy first)");
+    Rccl* r = rccl();
+    if (!r) return fail(IGT_E_STATE, "RCCL (librccl.so.1) could not be loaded");
+    HIPCHK(hipSetDevice(h->device));
+    IgtNcclId nid;
+    std::memcpy(nid.internal, id, IGT_COMM_ID_BYTES);
+    void* comm = nullptr;
+    if (int rc = r->CommInitRank(&comm, world, nid, rank)) return rccl_fail(r, "ncclCommInitRank", rc);
+    h->comm = comm; h->comm_world = world; h->comm_rank = rank;
+    return IGT_OK;
+}
+
+int igt_comm_destroy(igt_handle* h) {
+    if (!h) return fail(IGT_E_INVALID, "null handle");
+    if (!h->comm) return IGT_OK;
+    Rccl* r = rccl();
+    HIPCHK(hipSetDevice(h->device));
+    const int rc = r ? r->CommDestroy(h->comm) : 0;
+    h->comm = nullptr; h->comm_world = 1; h->comm_rank = 0;
+    return rc ? rccl_fail(r, "ncclCommDestroy", rc) : IGT_OK;
+}
+
+
+int igt_allgather_controls_f32(igt_handle* h, int32_t B_local, const float* u_out, float* u0_all, void* stream) {
+    return allgather_impl<float>(h, B_local, u_out, u0_all, stream);
+}
+int igt_allgather_controls_f64(igt_handle* h, int32_t B_local, const double* u_out, double* u0_all, void* stream) {
+    return allgather_impl<double>(h, B_local, u_out, u0_all, stream);
 }
 
 int igt_set_profiling(igt_handle* h, int enable) {

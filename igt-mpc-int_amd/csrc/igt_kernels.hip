@@ -1333,6 +1333,20 @@ template hipError_t launch_forecast<double>(const KP&, int, const double*, int, 
                                             const int32_t*, const double*, const double*, const int32_t*, double*, double*,
                                             hipStream_t);
 
+// u[B,2,N] -> u0[B,2] = u[:, :, 0]: the (a, df) each agent applies (evaluate.py:492), contiguous for the all-gather
+template <typename T>
+__global__ __launch_bounds__(256) void first_controls_kernel(int B, int N, const T* __restrict__ u, T* __restrict__ u0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * B) u0[i] = u[(size_t)i * N];
+}
+template <typename T>
+hipError_t launch_first_controls(int B, int N, const T* u, T* u0, hipStream_t st) {
+    hipLaunchKernelGGL((first_controls_kernel<T>), dim3((2 * B + 255) / 256), dim3(256), 0, st, B, N, u, u0);
+    return hipGetLastError();
+}
+template hipError_t launch_first_controls<float>(int, int, const float*, float*, hipStream_t);
+template hipError_t launch_first_controls<double>(int, int, const double*, double*, hipStream_t);
+
 template <typename T>
 hipError_t launch_cartesian(int n, int steps, double dt, double l_r, double l_f, const T* z0, const T* u, T* z_out,
                             hipStream_t st) {

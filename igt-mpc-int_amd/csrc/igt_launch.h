@@ -68,6 +68,7 @@ template <typename T>
 hipError_t launch_forecast(const KP& P, int B, const double* routes, int n_routes, const T* ego_xyh, const T* opp,
                            const T* opp_a, const int32_t* opp_route, const T* plan_x, const T* plan_u,
                            const int32_t* has_plan, T* obs_xy, T* tv_sv, hipStream_t st);
+template <typename T> hipError_t launch_first_controls(int B, int N, const T* u, T* u0, hipStream_t st);
 template <typename T>
 hipError_t launch_cartesian(int n, int steps, double dt, double l_r, double l_f, const T* z0, const T* u, T* z_out,
                             hipStream_t st);

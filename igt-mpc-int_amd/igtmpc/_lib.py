@@ -60,6 +60,11 @@ SYMBOLS = {
     'igt_frenet_step_f64': (_i, _FSTEP),
     'igt_cartesian_euler_f32': (_i, _CART),
     'igt_cartesian_euler_f64': (_i, _CART),
+    'igt_comm_unique_id': (_i, [_vp]),
+    'igt_comm_init': (_i, [_vp, _i32, _i32, _vp]),
+    'igt_comm_destroy': (_i, [_vp]),
+    'igt_allgather_controls_f32': (_i, [_vp, _i32, _vp, _vp, _vp]),
+    'igt_allgather_controls_f64': (_i, [_vp, _i32, _vp, _vp, _vp]),
     'igt_set_profiling': (_i, [_vp, _i]),
     'igt_get_kernel_ms': (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     'igt_algorithmic_bytes_per_solve': (_i, [_vp, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

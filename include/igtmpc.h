@@ -251,6 +251,25 @@ int igt_cartesian_euler_f32(igt_handle* h, int32_t n, int32_t T, const float* z0
 int igt_cartesian_euler_f64(igt_handle* h, int32_t n, int32_t T, const double* z0, const double* u,
                             double* z_out, int mem, void* stream);
 
+/* ---- multi-GPU: the one exchange of the path ---------------------------------------------------
+ * Scenarios are independent (evaluate.py:469-558: the agents of a timestep solve against the same predictions), so a
+ * batch shards into contiguous blocks, one process and one handle per GPU, with NO collective on the data path.  The
+ * only exchange is an all-gather of the first-step controls u*[:, :, 0] -- the (a, df) every agent applies
+ * (evaluate.py:492) -- so that each rank holds the whole action vector.  RCCL (ncclAllGather over xGMI) is bound at run
+ * time with dlopen: a single-GPU user needs no RCCL, and a host that already carries one (torch ships librccl.so.1,
+ * and `torch.distributed` is how bench.py and igtmpc/sharding.py do the same exchange) is not given a second copy.
+ *   igt_comm_unique_id : rank 0 creates the 128-byte id; the caller distributes it (MPI_Bcast, a file, a socket).
+ *   igt_comm_init      : every rank, same id; one communicator per handle.
+ *   igt_allgather_controls_* : u_out [B_local,2,N] (device) -> u0_all [world*B_local,2] (device), rank-major, enqueued
+ *                        on `stream`.  Equal shards (ncclAllGather); ragged shards are padded by the caller.  Without a
+ *                        communicator (world = 1) it reduces to the strided copy u0_all = u_out[:, :, 0]. */
+#define IGT_COMM_ID_BYTES 128
+int igt_comm_unique_id(void* id_out /* IGT_COMM_ID_BYTES */);
+int igt_comm_init(igt_handle* h, int32_t world, int32_t rank, const void* id);
+int igt_comm_destroy(igt_handle* h);
+int igt_allgather_controls_f32(igt_handle* h, int32_t B_local, const float* u_out, float* u0_all, void* stream);
+int igt_allgather_controls_f64(igt_handle* h, int32_t B_local, const double* u_out, double* u0_all, void* stream);
+
 /* Per-kernel timing with HIP events on the launch stream (used by bench.py for the
  * roofline line).  While enabled, every solve records events around its kernels;
  * igt_get_kernel_ms synchronises on them and returns the last call's durations. */

@@ -487,3 +487,35 @@ def test_closed_loop_matches_oracle_loop(cand_mode):
     # plans do (the retry branch itself is also pinned directly in test_forecast_matches_oracle)
     assert (ev['share_retry'] > 0) == (cand_mode == 'ramp_hold'), ev
     assert (ev['warm'] > 0) == (cand_mode == 'ramp_hold')
+
+
+def test_c_abi_allgather_controls_single_rank():
+    """igt_comm_* / igt_allgather_controls_* through ctypes on one GPU: without a communicator the gather is the strided
+    copy u*[:, :, 0]; with a world-of-one RCCL communicator (same ncclAllGather call every rank of an N-GPU job makes)
+    the result is the same.  The N > 1 exchange itself is covered by the gloo tests and bench.py --gpus N."""
+    import ctypes as ct
+    import torch
+    import igtmpc
+    from igtmpc import _lib as L
+    from igtmpc.scenarios import make_batch
+    b = make_batch(4096, dtype=np.float64)
+    dev = [torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda()
+           for a in (b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy'])]
+    with igtmpc.BatchSolver(dtype='f64') as s:
+        out = s.solve(*dev)
+        want = out['u'][:, :, 0].contiguous()
+        got = torch.full((4096, 2), -7.0, dtype=torch.float64, device='cuda')
+        st = torch.cuda.current_stream().cuda_stream or 1
+        L.check(s.lib.igt_allgather_controls_f64(s._h, 4096, out['u'].data_ptr(), got.data_ptr(), st))
+        torch.cuda.synchronize()
+        assert torch.equal(got.nan_to_num(), want.nan_to_num())
+        uid = (ct.c_char * 128)()
+        L.check(s.lib.igt_comm_unique_id(uid))
+        L.check(s.lib.igt_comm_init(s._h, 1, 0, uid))
+        with pytest.raises(igtmpc.IgtError):
+            L.check(s.lib.igt_comm_init(s._h, 1, 0, uid))          # already initialised
+        got2 = torch.full((4096, 2), -7.0, dtype=torch.float64, device='cuda')
+        L.check(s.lib.igt_allgather_controls_f64(s._h, 4096, out['u'].data_ptr(), got2.data_ptr(), st))
+        torch.cuda.synchronize()
+        assert torch.equal(got2.nan_to_num(), want.nan_to_num())
+        L.check(s.lib.igt_comm_destroy(s._h))
