@@ -568,12 +568,10 @@ int allgather_impl(igt_handle* h, int32_t B_local, const T* u_out, T* u0_all, vo
     if (!u_out || !u0_all) return fail(IGT_E_INVALID, "null buffer");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    const int world = h->comm ? h->comm_world : 1, rank = h->comm ? h->comm_rank : 0;
-    if (world == 1) {       // one shard: the gathered vector is the local one
+    if (!h->comm) {         // no communicator = one shard: the gathered vector is the local one
         HIPCHK(igt::launch_first_controls<T>(B_local, h->p.N, u_out, u0_all, st));
         return IGT_OK;
     }
-    (void)rank;
     const size_t bytes = (size_t)B_local * 2 * sizeof(T);
     if (bytes > h->u0_bytes) {
         if (capturing(st)) return fail(IGT_E_STATE, "staging buffer too small for stream capture: run one eager call first");
