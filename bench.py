@@ -191,6 +191,9 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip the other-precision block')
     ap.add_argument('--gt', type=int, default=0, metavar='SC',
                     help='gt_mpc cost with the shipped value net of scenario SC (1 or 3; BASELINE configs[4]); 0 = mpc cost')
+    ap.add_argument('--in-flight', type=int, default=1, choices=[1, 2, 3, 4],
+                    help='solves in flight: step t runs on handle/stream t mod F (each handle owns its workspace and '
+                         'output buffers), so the emit pass and the drain tail of one step overlap the search pass of the next')
     ap.add_argument('--rehearse-cpu', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus < 1:
@@ -249,11 +252,18 @@ def main():
         batch = make_batch(Bm, N=N, dtype=npdt, offset=rank * Bm)
         keys = ['x0', 'u_prev', 'kparams', 'flags', 'obs_xy'] + (['tv_sv', 'enc'] if args.gt else [])
         dargs = [torch.from_numpy(batch[k].view(np.int32) if batch[k].dtype == np.uint32 else batch[k]).cuda(dev) for k in keys]
-        solver = BatchSolver(N=N, C=C, n_obs=1, device=dev, dtype=dtype, cost_mode='value_net' if args.gt else 'progress')
-        solver.set_cinf(*cinf_halfplanes(dt=solver.params.dt, jerk=solver.params.jerk_limit))
-        if args.gt:
-            solver.set_value_net(layers)      # identity whitening: the reference's statistics are not shipped
-        out = solver.solve(*dargs)
+        F = args.in_flight
+        solvers, outs, lanes = [], [], []
+        for _ in range(F):
+            sv = BatchSolver(N=N, C=C, n_obs=1, device=dev, dtype=dtype, cost_mode='value_net' if args.gt else 'progress')
+            sv.set_cinf(*cinf_halfplanes(dt=sv.params.dt, jerk=sv.params.jerk_limit))
+            if args.gt:
+                sv.set_value_net(layers)      # identity whitening: the reference's statistics are not shipped
+            solvers.append(sv)
+            outs.append(sv.solve(*dargs))
+            lanes.append(torch.cuda.Stream(dev) if F > 1 else None)
+        torch.cuda.synchronize(dev)
+        solver, out = solvers[0], outs[0]
 
         # The one exchange of the path: all-gather of the first-step controls u*[:, :, 0] so that every rank
         # holds the full action vector.  A rank's next step does not depend on the other ranks' controls (scenarios are
@@ -271,12 +281,22 @@ def main():
         step_no = [0]
 
         def step():
-            solver.solve(*dargs, out=out)
+            if F > 1:       # step t on handle / stream t mod F; the inputs are read-only, every lane has its own outputs
+                q = step_no[0] % F
+                with torch.cuda.stream(lanes[q]):
+                    solvers[q].solve(*dargs, out=outs[q])
+                if not exchange:
+                    step_no[0] += 1
+                    return
+                main_s.wait_stream(lanes[q])
+            else:
+                q = 0
+                solver.solve(*dargs, out=out)
             if exchange:
                 i = step_no[0] & 1
                 step_no[0] += 1
                 main_s.wait_event(ev_free[i])                  # the exchange two steps back has released buffer i
-                u0_buf[i].copy_(out['u'][:, :, 0])
+                u0_buf[i].copy_(outs[q]['u'][:, :, 0])
                 ev_ready[i].record(main_s)
                 with torch.cuda.stream(comm):
                     comm.wait_event(ev_ready[i])
@@ -315,7 +335,8 @@ def main():
         res = dict(dtype=dtype, B=Bm, elapsed=elapsed, steps=steps, value=Bm * n_gpus * steps / elapsed,
                    ms_per_step=elapsed / steps * 1e3, search_ms=float(np.mean(ks)), emit_ms=float(np.mean(ke)),
                    rd=rd, wr=wr, feasible=float((out['status'] == 0).float().mean().item()), batch=batch)
-        solver.close()
+        for sv in solvers:
+            sv.close()
         return res
 
     head = measure(args.dtype, B, args.steps, args.warmup)
@@ -370,6 +391,7 @@ def main():
                        'parallelism': (f'scenario shards x{n_gpus}, one process per GPU, all-gather of u*[:, :, 0] on its own '
                                        f'stream under the next step') if exchange else 'single GPU',
                        'ranks_seen': world if exchange else 1, 'backend': backend,
+                       'solves_in_flight': args.in_flight,
                        'cost': f'gt_mpc value net V_GT_sc{args.gt} ({len(layers) - 1} hidden layers, identity normalisation)' if args.gt else 'mpc progress cost',
                        'feasible_fraction': head['feasible']},
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
