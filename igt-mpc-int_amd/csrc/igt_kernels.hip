@@ -829,6 +829,93 @@ __global__ __launch_bounds__(256) void rollout_all_f64_kernel(KP P, int B, const
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The LITERAL mapping of BASELINE.json's north_star, kept as a measurement variant (IGT_DEV_FLAGS = 2048):
+// one wavefront per (scenario, candidate) trajectory -- lane 0 rolls the horizon (the recurrence is sequential) and
+// stages the states in LDS; then the wave evaluates the stage costs and verdicts stage-parallel (lane k = stage k,
+// terminal-set facets spread over all 64 lanes), butterfly-reduces them, and the 16 waves of the scenario's workgroup
+// take the arg-min over the candidates.  DESIGN.md section 3 has the numbers: the roll-out is 63/64 idle, so this is
+// ~40x slower than one lane per candidate; it is NOT a production path (sum order differs from the oracle's).
+// ---------------------------------------------------------------------------------------
+struct LdsSink {
+    static constexpr bool kKeepsStates = true;
+    double* x;   // [7, N+1]
+    double* u;   // [2, N]
+    int N;
+    __device__ __forceinline__ void ctrl(int, int k, double a, double df) { u[k] = a; u[N + k] = df; }
+    __device__ __forceinline__ void state(int, int k, const double (&st)[7]) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) x[i * (N + 1) + k] = st[i];
+    }
+};
+constexpr int LIT_WAVES = 16, LIT_MAX_N = 40;
+template <int CAND, bool HI>
+__global__ __launch_bounds__(64 * LIT_WAVES) void search_literal_f64_kernel(
+    KP P, int B, int W, const double* __restrict__ x0, const double* __restrict__ u_prev, const double* __restrict__ kparams,
+    const uint32_t* __restrict__ flags, const double* __restrict__ obs, const double* __restrict__ table,
+    const double* __restrict__ cinf, Centre<double> cpar, double* __restrict__ part_J, int32_t* __restrict__ part_c) {
+    __shared__ double lds[LIT_WAVES][9 * (LIT_MAX_N + 1)];
+    __shared__ double wJ[LIT_WAVES];
+    __shared__ int wC[LIT_WAVES];
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    Scenario<double> S;
+    load_scenario<double>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
+    double* X = lds[wave];
+    double* U = X + 7 * (P.N + 1);
+    double bestJ = 0.0;
+    int bestC = -1;
+    for (int c = wave; c < P.C; c += LIT_WAVES) {
+        if (lane == 0) {                       // the trajectory: one lane, the other 63 wait
+            LdsSink sink{X, U, P.N};
+            double J, sN, vN;
+            unsigned viol;
+            f64::rollout_one<CAND, HI, false, true, LdsSink>(P, S, c, table, cinf, sink, J, viol, sN, vN);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        // stage-parallel cost (mpc.py:361-364) and verdicts (mpc.py:296-299, 316-317, 223-226): lane k = stage k
+        double part = 0.0, g = -1.0e300;
+        for (int k = lane; k <= P.N; k += 64) {
+            const double ey = X[3 * (P.N + 1) + k], ep = X[4 * (P.N + 1) + k], v = X[5 * (P.N + 1) + k];
+            part += ep * ep + ey * ey;
+            g = fmax(g, fabs(ey) - P.ey_lim);
+            if (k < P.N) {
+                const double a = U[k], df = U[P.N + k];
+                part += P.w_u * (a * a + df * df);
+                g = fmax(g, fmax(P.v_min - v, v - P.v_max));
+            }
+            if (k >= 1)
+                for (int o = 0; o < P.n_obs; ++o) {
+                    const double dx = X[k] - S.obs[(o * 2 + 0) * (P.N + 1) + k], dy = X[(P.N + 1) + k] - S.obs[(o * 2 + 1) * (P.N + 1) + k];
+                    g = fmax(g, P.dmin2 - (dx * dx + dy * dy));
+                }
+        }
+        {   // terminal set (mpc.py:177-180): the facets over the lanes
+            const double vt = X[5 * (P.N + 1) + P.N - 1], at = U[P.N - 1];
+            for (int m = lane; m < P.F; m += 64) g = fmax(g, cinf[m * 3 + 0] * vt + cinf[m * 3 + 1] * at - cinf[m * 3 + 2]);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            part += __shfl_xor(part, off, 64);
+            g = fmax(g, __shfl_xor(g, off, 64));
+        }
+        const double Jq = part - (X[2 * (P.N + 1) + P.N] - S.x0[2]);          // mpc.py:372
+        if (g <= P.tol && finite_d(Jq) && (bestC < 0 || Jq < bestJ)) { bestJ = Jq; bestC = c; }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) { wJ[wave] = bestJ; wC[wave] = bestC; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double J = 0.0;
+        int c = -1;
+        for (int w = 0; w < LIT_WAVES; ++w)
+            if (wC[w] >= 0 && (c < 0 || wJ[w] < J || (wJ[w] == J && wC[w] < c))) { J = wJ[w]; c = wC[w]; }
+        part_J[(size_t)b * W] = J; part_c[(size_t)b * W] = c;
+        for (int w = 1; w < W; ++w) part_c[(size_t)b * W + w] = -1;
+    }
+}
+
 // one control step for n independent states (kinematic_bicycle_model_frenet.py:70-127)
 template <class Stepper, typename T>
 __global__ __launch_bounds__(256) void frenet_step_kernel(KP P, int n, const T* __restrict__ x,
@@ -1022,7 +1109,7 @@ bool search_builds_queues(const KP& P, int B, const SolveArgs<float>& A) {
 }
 bool search_builds_queues(const KP& P, int B, const SolveArgs<double>& A) {
     const int W = P.C / 64;
-    return A.queue_order && W <= 256 && ((B + 7) / 8) * W <= QB_THREADS * QB_TRIPS && !(P.dev & 16) && !(P.dev & 1024);
+    return A.queue_order && W <= 256 && ((B + 7) / 8) * W <= QB_THREADS * QB_TRIPS && !(P.dev & 16) && !(P.dev & (1024 | 2048));
 }
 
 template <int CAND, bool HI, bool VALUE>
@@ -1076,6 +1163,11 @@ hipError_t launch_search<float>(const KP& P, int B, const SolveArgs<float>& A, i
 template <int CAND, bool HI, bool VALUE>
 static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A, hipStream_t st) {
     const int W = P.C / 64;
+    if ((P.dev & 2048) && !VALUE && P.N <= LIT_MAX_N) {       // measurement variant: the literal wave-per-trajectory mapping
+        hipLaunchKernelGGL((search_literal_f64_kernel<CAND, HI>), dim3(B), dim3(64 * LIT_WAVES), 0, st, P, B, W, A.x0, A.u_prev,
+                           A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c);
+        return hipGetLastError();
+    }
     const size_t total = (size_t)B * W;
     // 3 waves per SIMD from 16 units per wave slot upwards, else 2 (same rule as the float kernels)
     const bool big = total >= (size_t)A.n_cu * 12 * 16;

@@ -64,3 +64,7 @@ if __name__ == '__main__':
             print(f'   production vs oracle-order kernels: arg-min equal {same.mean():.5f}, max rel dx {ex.max():.2e}, '
                   f'max rel dcost {ec.max():.2e}', flush=True)
         run(B, 0, dtype='f32')
+        if B <= 4096:     # the literal north_star mapping (one wave per trajectory, stages in LDS), measurement variant
+            lit = run(B, 2048, iters=2)
+            same = fast['argmin'] == lit['argmin']
+            print(f'   literal wave-per-trajectory variant: arg-min equal to production on {same.mean():.5f} of the scenarios', flush=True)
