@@ -285,7 +285,7 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     {
         const size_t n_rec = value ? (size_t)B * p.C : 0;
         const size_t need = (size_t)B * W * 12 + (size_t)B * 56 + 8192 + ckpt_bytes + (size_t)(B + 8) * Wk * 36 + 256 + n_rec * (2 * sizeof(T) + 16) +
-                            (value ? (size_t)B * igt::VN_H * sizeof(T) : 0) + 16 * 256;
+                            (value ? (size_t)B * igt::VN_H * sizeof(T) + (size_t)B * Wk * 8 : 0) + 20 * 256;
         if (int rc = ensure_work(h, need, st)) return rc;
         Arena wa{(char*)h->d_work, 0};
         A.part_J = wa.take<double>((size_t)B * W);
@@ -309,6 +309,7 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
             A.rec_b = wa.take<int32_t>(n_rec);
             A.rec_count = wa.take<unsigned>(64);
             A.best_key = wa.take<unsigned long long>((size_t)B);
+            A.unit_seg = wa.take<int2>((size_t)B * Wk);
         }
     }
     if (h->prof) HIPCHK(hipEventRecord(h->ev[0], st));
@@ -322,7 +323,10 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
                 HIPCHK(hipMemsetAsync(A.rec_count, 0, 256, st));
                 HIPCHK(hipMemsetAsync(A.best_key, 0xff, (size_t)B * 8, st));
             }
-            else if (!exact64 && !counters_by_builder(kp, B, A)) HIPCHK(hipMemsetAsync(A.work_counter, 0, 8 * 256, st));
+            else if (!exact64) {      // double path: compact list of feasible candidates as well
+                if (!counters_by_builder(kp, B, A)) HIPCHK(hipMemsetAsync(A.work_counter, 0, 8 * 256, st));
+                HIPCHK(hipMemsetAsync(A.rec_count, 0, 256, st));
+            }
             HIPCHK(igt::launch_search_records<T>(kp, B, A, st));
             HIPCHK(igt::launch_value<T>(kp, B, net_of<T>(h), A, nullptr, nullptr, st));
             if (exact64) HIPCHK(igt::launch_reduce<T>(B, (int)W, A, st));
@@ -782,15 +786,42 @@ int igt_set_value_net(igt_handle* h, int32_t n_layers, const int32_t* dims, cons
             for (int r = 0; r < 16; ++r)
                 for (int hh = 0; hh < 2; ++hh) *f++ = (float)Wo[32 * t + igt::frag_row(r, hh)];
     }
+    // double block = the plain arrays followed by the f64 MFMA fragment block (igt_value_net.h, value_mfma_f64_kernel):
+    // lane (i = l & 15, g = l >> 4) of k-step (T, r) holds W[16 To + i][16 T + 4 r + g]
+    const size_t nfragd = (size_t)igt::fragd_doubles(nm);
+    blk.resize(n + nfragd);
+    A1 = blk.data(); c1 = A1 + (size_t)H * 6;            // (the resize may have moved the block)
+    {
+        double* f = blk.data() + n;
+        for (int t = 0; t < 8; ++t)                       // A1F: [A1 | c1 | 0]
+            for (int s2 = 0; s2 < 2; ++s2)
+                for (int l = 0; l < 64; ++l) {
+                    const int i = 16 * t + (l & 15), k = 4 * s2 + (l >> 4);
+                    *f++ = k < 6 ? A1[i * 6 + k] : (k == 6 ? c1[i] : 0.0);
+                }
+        for (int m = 0; m < nm; ++m)                      // WF[m]
+            for (int t = 0; t < 8; ++t)
+                for (int ti = 0; ti < 8; ++ti)
+                    for (int r = 0; r < 4; ++r)
+                        for (int l = 0; l < 64; ++l)
+                            *f++ = Wh[m][(size_t)(16 * t + (l & 15)) * H + (16 * ti + 4 * r + (l >> 4))];
+        for (int m = 0; m < nm; ++m)                      // BF[m]: bias of row 16 t + g + 4 r
+            for (int t = 0; t < 8; ++t)
+                for (int r = 0; r < 4; ++r)
+                    for (int g = 0; g < 4; ++g) *f++ = bh[m][16 * t + g + 4 * r];
+        for (int t = 0; t < 8; ++t)                       // WOF
+            for (int r = 0; r < 4; ++r)
+                for (int g = 0; g < 4; ++g) *f++ = Wo[16 * t + g + 4 * r];
+    }
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->d_net) { HIPCHK(hipFree(h->d_net)); h->d_net = nullptr; }
     const size_t bytes_f = (((n + nfrag) * 4 + 255) / 256) * 256;
-    HIPCHK(hipMalloc(&h->d_net, bytes_f + n * 8));
+    HIPCHK(hipMalloc(&h->d_net, bytes_f + (n + nfragd) * 8));
     float* df = reinterpret_cast<float*>(h->d_net);
     double* dd = reinterpret_cast<double*>(reinterpret_cast<char*>(h->d_net) + bytes_f);
     HIPCHK(hipMemcpy(df, blkf.data(), (n + nfrag) * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dd, blk.data(), n * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dd, blk.data(), (n + nfragd) * 8, hipMemcpyHostToDevice));
     auto fill = [&](auto& net, auto* base) {
         net.A1 = base; net.c1 = base + (size_t)H * 6;
         for (int m = 0; m < 2; ++m) { net.WT[m] = m < nm ? base + offWT[m] : nullptr; net.bias[m] = m < nm ? base + offB[m] : nullptr; }
@@ -799,8 +830,8 @@ int igt_set_value_net(igt_handle* h, int32_t n_layers, const int32_t* dims, cons
     };
     fill(h->net_f, df);
     fill(h->net_d, dd);
-    h->net_f.frag = df + n;
-    h->net_d.frag = nullptr;
+    h->net_f.frag = df + n; h->net_f.fragd = nullptr;
+    h->net_d.frag = nullptr; h->net_d.fragd = dd + n;
     h->net_f.bout = (float)bo; h->net_f.sigma_t = (float)sigma_t; h->net_f.mu_t = (float)mu_t;
     h->net_d.bout = bo; h->net_d.sigma_t = sigma_t; h->net_d.mu_t = mu_t;
     HIPCHK(igt::prepare_value_kernels(nm));

@@ -700,7 +700,8 @@ __device__ __forceinline__ int slice_candidate64(const KP& P, int W, int p, int 
         const double* __restrict__ kparams, const uint32_t* __restrict__ flags, const double* __restrict__ obs,      \
         const double* __restrict__ table, const double* __restrict__ cinf, Centre<double> cpar,          \
         double* __restrict__ part_J, int32_t* __restrict__ part_c, double* __restrict__ rec_sN,                      \
-        double* __restrict__ rec_vN, double* __restrict__ rec_J, uint32_t* __restrict__ rec_viol
+        double* __restrict__ rec_vN, double* __restrict__ rec_J, uint32_t* __restrict__ rec_viol,                    \
+        unsigned* __restrict__ rec_count, int32_t* __restrict__ rec_b, int2* __restrict__ unit_seg
 
 // One work unit = one (scenario, 64-candidate slice), rolled by one wave; leaves the slice's best (J, c), or -- value-net
 // cost -- every candidate's record for value_kernel<double> (mpc.py:369).
@@ -712,7 +713,8 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
                                               Centre<double> cpar, double* __restrict__ part_J,
                                               int32_t* __restrict__ part_c, double* __restrict__ rec_sN,
                                               double* __restrict__ rec_vN, double* __restrict__ rec_J,
-                                              uint32_t* __restrict__ rec_viol) {
+                                              uint32_t* __restrict__ rec_viol, unsigned* __restrict__ rec_count,
+                                              int32_t* __restrict__ rec_b, int2* __restrict__ unit_seg) {
     const int lane = threadIdx.x & 63;
     Scenario<double> S;
     load_scenario<double>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
@@ -721,9 +723,19 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
     double J, sN, vN;
     unsigned viol;
     f64::rollout_one<CAND, HI, true, true, NullSink, true>(P, S, c, table, cinf, sink, J, viol, sN, vN);
-    if (VALUE) {
-        const size_t idx = (size_t)b * P.C + c;
-        rec_sN[idx] = sN; rec_vN[idx] = vN; rec_J[idx] = J; rec_viol[idx] = viol;
+    if (VALUE) {   // terminal value network (mpc.py:369): append the feasible candidates for value_mfma_f64_kernel; the
+                   // unit's entries are contiguous, unit_seg remembers where (unit_reduce_kernel picks the unit's best)
+        const bool ok = viol == 0 && finite_d(J);
+        const unsigned long long m = __ballot(ok);
+        const unsigned n = __popcll(m);
+        unsigned base = 0;
+        if (lane == 0 && n) base = atomicAdd(rec_count, n);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (ok) {
+            const unsigned e = base + __popcll(m & ((1ull << lane) - 1ull));
+            rec_b[e] = b; reinterpret_cast<int32_t*>(rec_viol)[e] = c; rec_sN[e] = sN; rec_vN[e] = vN; rec_J[e] = J;
+        }
+        if (lane == 0) unit_seg[b * W + p] = make_int2((int)base, (int)n);
         return;
     }
     const double Jq = J - (sN - S.x0[2]);                       // mpc.py:372
@@ -744,14 +756,14 @@ template <int CAND, bool HI, bool VALUE>
 __global__ __launch_bounds__(64) void search_f64_kernel_o2(IGT_SEARCH64_ARGS) {
     search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
         search_unit64<CAND, HI, VALUE>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN,
-                                       rec_vN, rec_J, rec_viol);
+                                       rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg);
     });
 }
 template <int CAND, bool HI, bool VALUE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void search_f64_kernel_o3(IGT_SEARCH64_ARGS) {
     search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
         search_unit64<CAND, HI, VALUE>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN,
-                                       rec_vN, rec_J, rec_viol);
+                                       rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg);
     });
 }
 
@@ -1184,11 +1196,11 @@ static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A
     if (o3)
         hipLaunchKernelGGL((search_f64_kernel_o3<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter, order,
                            order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c,
-                           A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
+                           A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b, A.unit_seg);
     else
         hipLaunchKernelGGL((search_f64_kernel_o2<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter, order,
                            order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c,
-                           A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
+                           A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b, A.unit_seg);
     return hipGetLastError();
 }
 template <bool VALUE>
@@ -1225,6 +1237,12 @@ hipError_t prepare_value_kernels(int n_hidden_mats) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_kernel<double>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_mfma_f64_kernel<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FRAGD_W * sizeof(double)));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_mfma_f64_kernel<2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FRAGD_W * sizeof(double)));
+    if (e != hipSuccess) return e;
     const size_t lds_f = (size_t)frag_floats(n_hidden_mats) * sizeof(float);
     if (n_hidden_mats > 1)
         return hipFuncSetAttribute(reinterpret_cast<const void*>(&value_mfma_kernel<2>),
@@ -1239,6 +1257,21 @@ hipError_t launch_value(const KP& P, int B, const DevNet<T>& net, const SolveArg
 template <>
 hipError_t launch_value<double>(const KP& P, int B, const DevNet<double>& net, const SolveArgs<double>& A,
                                 double* cost_all, uint32_t* viol_all, hipStream_t st) {
+    if (!cost_all && !(P.dev & 1024)) {   // solve path: the compact list of feasible candidates on the f64 matrix cores
+        const size_t lds = (size_t)FRAGD_W * sizeof(double);
+        if (net.n_hidden_mats > 1)
+            hipLaunchKernelGGL(value_mfma_f64_kernel<2>, dim3(A.n_cu), dim3(512), lds, st, net, A.rec_count, A.rec_b, A.rec_sN,
+                               A.rec_vN, A.rec_J, A.tv_sv, A.enc);
+        else
+            hipLaunchKernelGGL(value_mfma_f64_kernel<1>, dim3(A.n_cu), dim3(512), lds, st, net, A.rec_count, A.rec_b, A.rec_sN,
+                               A.rec_vN, A.rec_J, A.tv_sv, A.enc);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const int n_units = B * (P.C / 64);
+        hipLaunchKernelGGL(unit_reduce_kernel, dim3((n_units + 255) / 256), dim3(256), 0, st, n_units, A.unit_seg, A.rec_J,
+                           reinterpret_cast<const int32_t*>(A.rec_viol), A.part_J, A.part_c);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((value_prep_kernel<double>), dim3(B), dim3(VN_H), 0, st, B, net, A.tv_sv, A.enc, A.p_vec);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -43,6 +43,7 @@ struct SolveArgs {   // all device pointers
     unsigned* rec_count;
     int32_t* rec_b;
     unsigned long long* best_key;   // [B] per-scenario (orderable cost, candidate) minimum
+    int2* unit_seg;                 // double path: [B, C/64] (first entry, count) of each unit's entries in the compact list
 };
 
 bool search_builds_queues(const KP& P, int B, const SolveArgs<float>& A);   // then no memset of the counters is needed

@@ -27,13 +27,18 @@ struct DevNet {                // device pointers, all wave-uniform
     const T* wout;             // [128]
     T bout, sigma_t, mu_t;
     int n_hidden_mats;         // 1 (two hidden layers) or 2 (three hidden layers)
-    const float* frag;         // MFMA fragment block (float nets only; see value_mfma_kernel)
+    const float* frag;         // f32 MFMA fragment block (float net only; see value_mfma_kernel)
+    const double* fragd;       // f64 MFMA fragment block (double net only; see value_mfma_f64_kernel)
 };
 
 // MFMA fragment block of the float net (layout: value_mfma_kernel)
 constexpr int FRAG_A1 = 4 * 4 * 64, FRAG_W = 4 * 64 * 64, FRAG_B = 4 * 16 * 2;
 __host__ __device__ constexpr int frag_floats(int nm) { return FRAG_A1 + nm * FRAG_W + nm * FRAG_B + FRAG_B; }
 __host__ __device__ constexpr int frag_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }   // C/D row of register r
+
+// f64 MFMA fragment block of the double net (layout: value_mfma_f64_kernel), in doubles
+constexpr int FRAGD_A1 = 8 * 2 * 64, FRAGD_W = 8 * 8 * 4 * 64, FRAGD_B = 8 * 4 * 4;
+__host__ __device__ constexpr int fragd_doubles(int nm) { return FRAGD_A1 + nm * FRAGD_W + nm * FRAGD_B + FRAGD_B; }
 
 template <typename T> __device__ __forceinline__ T tanh_t(T x);
 template <> __device__ __forceinline__ float tanh_t<float>(float x) { return tanhf(x); }
@@ -403,6 +408,139 @@ __global__ __launch_bounds__(512) void value_mfma_kernel(DevNet<float> net, Comp
         v += __shfl_xor(v, 32, 64);
         compact_finish(net, live && half == 0, b, c, J, v + net.bout, best_key);
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// The double net over the compact list on the matrix cores: v_mfma_f64_16x16x4_f64 (f64 in, f64 accumulate).
+// Same transposed formulation as the float kernel, X = [neuron x candidate], a layer is Y = W X.  With this
+// instruction the chain needs no re-ordering at all: a lane (g = lane >> 4, col = lane & 15) holds rows g + 4 r of a
+// 16 x 16 output tile in its 4 result registers, and as B operand of a k-step it must supply row k = g -- so result
+// register r of tile T IS the B operand of the k-step that covers neurons 16 T + 4 r + (0..3), as it stands.
+//   wave = 16 candidates (the 4 lanes of a column hold the same candidate, different rows)
+//   layer 1:  [128 x 8] x [8 x 16], features (f0..f5, 1, 0): the bias rides as the 7th feature     16 MFMA
+//   hidden :  8 output tiles x 32 k-steps, accumulators start at the bias fragment                  256 MFMA each
+//   output :  32 FMAs per lane + two cross-lane adds
+// fragd block (doubles): A1F[8][2][64] | WF[m][8][8][4][64] | BF[m][8][4][4] | WOF[8][4][4]; the first hidden matrix
+// (128 KB) is staged in LDS, a second one is read through L2.  tanh = 1 - 2/(exp(2x)+1) with a double exp
+// (Cody-Waite reduction, degree-12 polynomial, v_ldexp_f64): absolute error ~2e-16.
+// ---------------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double tanh_d(double x) {
+    const double y = fmin(fmax(2.0 * x, -80.0), 80.0);
+    const double n = __builtin_rint(y * 1.4426950408889634);
+    double r = fma(-n, 6.93147180369123816490e-01, y);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p = fma(r, 1.0 / 479001600.0, 1.0 / 39916800.0);
+    p = fma(r, p, 1.0 / 3628800.0);
+    p = fma(r, p, 1.0 / 362880.0);
+    p = fma(r, p, 1.0 / 40320.0);
+    p = fma(r, p, 1.0 / 5040.0);
+    p = fma(r, p, 1.0 / 720.0);
+    p = fma(r, p, 1.0 / 120.0);
+    p = fma(r, p, 1.0 / 24.0);
+    p = fma(r, p, 1.0 / 6.0);
+    p = fma(r, p, 0.5);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    const double e = ldexp(p, (int)n) + 1.0;                  // exp(2x) + 1
+    double q = __builtin_amdgcn_rcp(e);
+    q = fma(fma(-e, q, 1.0), q, q);
+    q = fma(fma(-e, q, 1.0), q, q);
+    return fma(-2.0, q, 1.0);
+}
+
+template <int NM>
+__global__ __launch_bounds__(512) void value_mfma_f64_kernel(DevNet<double> net, const unsigned* __restrict__ rec_count,
+                                                             const int32_t* __restrict__ rec_b,
+                                                             const double* __restrict__ rec_sN,
+                                                             const double* __restrict__ rec_vN, double* __restrict__ rec_J,
+                                                             const double* __restrict__ tv_sv, const double* __restrict__ enc) {
+    extern __shared__ double ldsd[];
+    const double* __restrict__ A1F = net.fragd;
+    const double* __restrict__ WFg = A1F + FRAGD_A1;
+    const double* __restrict__ BF = WFg + NM * FRAGD_W;
+    const double* __restrict__ WOF = BF + NM * FRAGD_B;
+    for (int i = threadIdx.x; i < FRAGD_W; i += 512) ldsd[i] = WFg[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
+    const unsigned count = *rec_count;
+    const unsigned wave = blockIdx.x * 8u + (threadIdx.x >> 6), nwaves = gridDim.x * 8u;
+    for (unsigned base = wave * 16u; base < count; base += nwaves * 16u) {
+        const unsigned e = base + (unsigned)col;
+        const bool live = e < count;
+        const int b = live ? rec_b[e] : 0;
+        const double sN = live ? rec_sN[e] : 0.0, vN = live ? rec_vN[e] : 0.0;
+        const double s_tv = tv_sv[(size_t)b * 2 + 0], v_tv = tv_sv[(size_t)b * 2 + 1];
+        const double e_ego = enc[(size_t)b * 2 + 0], e_tv = enc[(size_t)b * 2 + 1];
+        // x_N = [s_tv, v_tv, e_tv, s_N - s_tv, v_N - v_tv, e_ego - e_tv]   (mpc.py:326-338); B operand: feature 4 s + g
+        const double x0 = g == 0 ? s_tv : g == 1 ? v_tv : g == 2 ? e_tv : sN - s_tv;
+        const double x1 = g == 0 ? vN - v_tv : g == 1 ? e_ego - e_tv : g == 2 ? 1.0 : 0.0;
+        f64x4 Ha[8], Hb[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A1F[(t * 2 + 0) * 64 + lane], x0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A1F[(t * 2 + 1) * 64 + lane], x1, acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ha[t][r] = tanh_d(acc[r]);
+        }
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                f64x4 acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = BF[m * FRAGD_B + (t * 4 + r) * 4 + g];
+#pragma unroll
+                for (int ti = 0; ti < 8; ++ti) {
+                    double afr[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int idx = ((t * 8 + ti) * 4 + r) * 64 + lane;
+                        afr[r] = (m == 0) ? ldsd[idx] : WFg[(size_t)m * FRAGD_W + idx];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double bop = (m == 0) ? Ha[ti][r] : Hb[ti][r];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[r], bop, acc, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (m == 0) Hb[t][r] = tanh_d(acc[r]); else Ha[t][r] = tanh_d(acc[r]);
+                }
+            }
+        }
+        double v = 0.0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double hv = (NM == 1) ? Hb[t][r] : Ha[t][r];
+                v = fma(WOF[(t * 4 + r) * 4 + g], hv, v);
+            }
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (live && g == 0) rec_J[e] = rec_J[e] - ((v + net.bout) * net.sigma_t + net.mu_t);      // mpc.py:369
+    }
+}
+
+// a unit's entries of the compact list (contiguous: [base, base + n)) -> the unit's best (J, c)
+__global__ __launch_bounds__(256) void unit_reduce_kernel(int n_units, const int2* __restrict__ unit_seg,
+                                                          const double* __restrict__ rec_J, const int32_t* __restrict__ rec_c,
+                                                          double* __restrict__ part_J, int32_t* __restrict__ part_c) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_units) return;
+    const int2 sg = unit_seg[u];
+    double J = 0.0;
+    int c = -1;
+    for (int e = sg.x; e < sg.x + sg.y; ++e) {
+        const double Je = rec_J[e];
+        const int ce = rec_c[e];
+        if (fabs(Je) < 1.79e308 && (c < 0 || Je < J || (Je == J && ce < c))) { J = Je; c = ce; }
+    }
+    part_J[u] = J; part_c[u] = c;
 }
 
 // best_key[B] -> one partial per scenario (part_J, part_c with W = 1) for refine / emit
