@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- MPC solves/s of the batched shooting solver (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype f64|f32] [--gt SC]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype f64|f32] [--gt SC] [--in-flight F]
 
 One "step" = one pass of the hot path over one batch of synthetic two-vehicle intersection
 scenarios per GPU (SURVEY.md section 8d generator), inputs already resident in HBM:
@@ -13,6 +13,12 @@ The headline (`value`, `dtype`) is the float64 entry igt_solve_batch_f64 -- the 
 (kinematic_bicycle_model_frenet.py:70-127 and mpc.py are float64 end to end); the float32 entry
 (float stage derivatives, double state accumulators) is timed in the same run and reported beside it as
 `f32_path`.
+
+Steps are pipelined (`--in-flight F`, default 4): step t is enqueued on handle / stream t mod F -- every handle owns
+its workspace and its output buffers, the inputs are read-only -- so the emit pass (one roll-out of latency) and the
+drain tail of one step's search overlap the search pass of the next instead of being exposed.  All K steps complete
+inside the timed region; the one-solve-at-a-time figure (`--in-flight 1`) is measured in the same run and printed as
+`one_solve_in_flight`.
 
 N > 1: one process per GPU, each solving its own contiguous shard (weak scaling, no data-path collective).
 The driver launches that as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`; a plain
@@ -191,7 +197,7 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip the other-precision block')
     ap.add_argument('--gt', type=int, default=0, metavar='SC',
                     help='gt_mpc cost with the shipped value net of scenario SC (1 or 3; BASELINE configs[4]); 0 = mpc cost')
-    ap.add_argument('--in-flight', type=int, default=1, choices=[1, 2, 3, 4],
+    ap.add_argument('--in-flight', type=int, default=4, choices=[1, 2, 3, 4],
                     help='solves in flight: step t runs on handle/stream t mod F (each handle owns its workspace and '
                          'output buffers), so the emit pass and the drain tail of one step overlap the search pass of the next')
     ap.add_argument('--rehearse-cpu', action='store_true', help=argparse.SUPPRESS)
@@ -245,14 +251,14 @@ def main():
             layers.append((g[f'sc{args.gt}_W{i}'], g[f'sc{args.gt}_b{i}']))
             i += 1
 
-    def measure(dtype, Bm, steps, warmup):
+    def measure(dtype, Bm, steps, warmup, in_flight=None):
         """W untimed + K timed steps of the `dtype` entry point at Bm scenarios per GPU, then per-kernel HIP events."""
         npdt = np.float64 if dtype == 'f64' else np.float32
         td = torch.float64 if dtype == 'f64' else torch.float32
         batch = make_batch(Bm, N=N, dtype=npdt, offset=rank * Bm)
         keys = ['x0', 'u_prev', 'kparams', 'flags', 'obs_xy'] + (['tv_sv', 'enc'] if args.gt else [])
         dargs = [torch.from_numpy(batch[k].view(np.int32) if batch[k].dtype == np.uint32 else batch[k]).cuda(dev) for k in keys]
-        F = args.in_flight
+        F = in_flight or args.in_flight
         solvers, outs, lanes = [], [], []
         for _ in range(F):
             sv = BatchSolver(N=N, C=C, n_obs=1, device=dev, dtype=dtype, cost_mode='value_net' if args.gt else 'progress')
@@ -347,6 +353,8 @@ def main():
     same_work = None
     if n_gpus > 1 and B != default_batch(1) and not args.batch:
         same_work = measure(args.dtype, default_batch(1), args.steps, args.warmup)
+    # one solve at a time (every step waits for the previous one's emit pass), for comparison with the pipelined headline
+    serial = measure(args.dtype, B, args.steps, args.warmup, in_flight=1) if args.in_flight > 1 and not args.no_secondary else None
 
     if rank == 0:
         search_ms, emit_ms, rd = head['search_ms'], head['emit_ms'], head['rd']
@@ -392,6 +400,8 @@ def main():
                                        f'stream under the next step') if exchange else 'single GPU',
                        'ranks_seen': world if exchange else 1, 'backend': backend,
                        'solves_in_flight': args.in_flight,
+                       'pipelining': (f'step t runs on handle / stream t mod {args.in_flight} (own workspace and output buffers each); '
+                                      f'all {args.steps} steps complete inside the timed region') if args.in_flight > 1 else 'none',
                        'cost': f'gt_mpc value net V_GT_sc{args.gt} ({len(layers) - 1} hidden layers, identity normalisation)' if args.gt else 'mpc progress cost',
                        'feasible_fraction': head['feasible']},
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -414,6 +424,11 @@ def main():
                 'kernels_ms': {'search': other['search_ms'], 'emit': other['emit_ms']},
                 'steps': args.steps, 'warmup': args.warmup, 'feasible_fraction': other['feasible'],
                 'note': 'same workload, same run, timed exactly like the headline'}
+        if serial is not None:
+            line['one_solve_in_flight'] = {
+                'value': serial['value'], 'ms_per_step': serial['ms_per_step'], 'dtype': args.dtype,
+                'note': 'same workload and entry point with --in-flight 1: step t+1 is enqueued behind step t on one stream, '
+                        'so every emit pass and every search drain tail is exposed'}
         if same_work is not None:
             line['same_per_gpu_work_as_n1'] = {
                 'per_gpu_batch': same_work['B'], 'value': same_work['value'], 'ms_per_step': same_work['ms_per_step'],
