@@ -364,7 +364,7 @@ def main():
         # come from the committed rocprofv3 --pmc passes of this same command and are quoted only when the profile was
         # collected at the kernel sources this library was built from -- otherwise null.
         traffic, valu_insts, pmc_src = None, None, None
-        tpath = os.path.join(ROOT, 'profiles', f'r02_pmc_{args.dtype}_b{B}{"_gt%d" % args.gt if args.gt else ""}.json')
+        tpath = os.path.join(ROOT, 'profiles', f'r02_pmc_{args.dtype}{"_gt%d" % args.gt if args.gt else ""}_b{B}.json')
         if os.path.exists(tpath):
             try:
                 with open(tpath) as f:

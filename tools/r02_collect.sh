@@ -1,23 +1,30 @@
 #!/bin/bash
-# Runs on the GPU box: the round's evidence in one call -- bench lines and the rocprofv3 passes behind profiles/.
-#   usage: tools/r02_collect.sh <tag>
+# Runs on the GPU box: the round's evidence in one call -- bench lines, probes and the rocprofv3 passes behind profiles/.
+#   usage: tools/r02_collect.sh <tag>        then, back home:  python tools/r02_publish.py <tag>
 TAG=${1:-r02}
 export TMPDIR=/tmp
-python3 bench.py > gpurun_out/${TAG}_bench_b4096.json 2> gpurun_out/${TAG}_bench_b4096.err
+O=gpurun_out
+python3 bench.py > $O/${TAG}_bench_b4096.json 2> $O/${TAG}_bench_b4096.err
 echo "[collect] bench 4096 done"
-python3 bench.py --in-flight 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_b4096_f2.json 2> gpurun_out/${TAG}_bench_b4096_f2.err
-python3 bench.py --in-flight 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_b4096_f3.json 2> gpurun_out/${TAG}_bench_b4096_f3.err
-echo "[collect] bench 4096 in-flight 2/3 done"
-python3 bench.py --batch 65536 --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_b65536.json 2> gpurun_out/${TAG}_bench_b65536.err
-echo "[collect] bench 65536 done"
-python3 bench.py --batch 65536 --gt 1 --steps 30 --warmup 5 > gpurun_out/${TAG}_bench_gt_sc1_b65536.json 2> gpurun_out/${TAG}_bench_gt1.err
-python3 bench.py --batch 65536 --gt 3 --steps 30 --warmup 5 > gpurun_out/${TAG}_bench_gt_sc3_b65536.json 2> gpurun_out/${TAG}_bench_gt3.err
-echo "[collect] bench gt done"
-IGT_PMC_DTYPE=f64 IGT_PMC_BATCH=4096 tools/pmc_collect.sh ${TAG}_f64_b4096 > gpurun_out/${TAG}_collect_f64_b4096.log 2>&1
+python3 bench.py --batch 65536 --steps 40 --warmup 5 --no-cpu-baseline --in-flight 1 > $O/${TAG}_bench_b65536.json 2> $O/${TAG}_bench_b65536.err
+python3 bench.py --batch 65536 --gt 1 --steps 30 --warmup 5 --in-flight 1 > $O/${TAG}_bench_gt_sc1_b65536.json 2> $O/${TAG}_bench_gt1.err
+python3 bench.py --batch 65536 --gt 3 --steps 30 --warmup 5 --in-flight 1 > $O/${TAG}_bench_gt_sc3_b65536.json 2> $O/${TAG}_bench_gt3.err
+echo "[collect] bench 65536 / gt done"
+for F in 1 2 3 4; do
+  python3 bench.py --in-flight $F --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('in-flight $F: f64 %.3f ms/step (%.2f M solves/s)   f32 %.3f ms/step (%.2f M solves/s)' % (d['ms_per_step'], d['value']/1e6, d['f32_path']['ms_per_step'], d['f32_path']['value']/1e6))"
+done > $O/${TAG}_inflight_sweep.txt
+echo "[collect] in-flight sweep done"
+python3 tools/f64_probe.py 4096 32768 2>&1 | grep -v amdgpu.ids > $O/${TAG}_f64_probe.txt
+python3 tools/f64_probe.py --flags=0,8 65536 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_f64_probe.txt
+python3 tools/f32_margin_probe.py 2048 2>&1 | grep -v amdgpu.ids > $O/${TAG}_f32_margin.txt
+python3 tools/closed_loop_probe.py f64 > $O/${TAG}_closed_loop.txt 2>&1
+echo "[collect] probes done"
+IGT_PMC_DTYPE=f64 IGT_PMC_BATCH=4096 tools/pmc_collect.sh ${TAG}_f64_b4096 > $O/${TAG}_collect_f64_b4096.log 2>&1
 echo "[collect] pmc f64 4096 done"
-IGT_PMC_DTYPE=f64 IGT_PMC_BATCH=65536 tools/pmc_collect.sh ${TAG}_f64_b65536 --batch 65536 --steps 8 --warmup 2 --no-cpu-baseline --no-secondary > gpurun_out/${TAG}_collect_f64_b65536.log 2>&1
+IGT_PMC_DTYPE=f64 IGT_PMC_BATCH=65536 tools/pmc_collect.sh ${TAG}_f64_b65536 --batch 65536 --steps 8 --warmup 2 --no-cpu-baseline --no-secondary --in-flight 1 > $O/${TAG}_collect_f64_b65536.log 2>&1
 echo "[collect] pmc f64 65536 done"
-IGT_PMC_DTYPE=f32 IGT_PMC_BATCH=4096 tools/pmc_collect.sh ${TAG}_f32_b4096 --dtype f32 --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > gpurun_out/${TAG}_collect_f32_b4096.log 2>&1
+IGT_PMC_DTYPE=f32 IGT_PMC_BATCH=4096 tools/pmc_collect.sh ${TAG}_f32_b4096 --dtype f32 --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --in-flight 1 > $O/${TAG}_collect_f32_b4096.log 2>&1
 echo "[collect] pmc f32 4096 done"
-IGT_PMC_DTYPE=f32 IGT_PMC_BATCH=65536 tools/pmc_collect.sh ${TAG}_f32_gt1_b65536 --dtype f32 --gt 1 --batch 65536 --steps 8 --warmup 2 --no-secondary > gpurun_out/${TAG}_collect_f32_gt1.log 2>&1
-echo "[collect] pmc f32 gt 65536 done"
+IGT_PMC_DTYPE=f32 IGT_PMC_BATCH=65536 tools/pmc_collect.sh ${TAG}_f32_gt1_b65536 --dtype f32 --gt 1 --batch 65536 --steps 8 --warmup 2 --no-secondary --no-cpu-baseline --in-flight 1 > $O/${TAG}_collect_f32_gt1.log 2>&1
+IGT_PMC_DTYPE=f64 IGT_PMC_BATCH=65536 tools/pmc_collect.sh ${TAG}_f64_gt1_b65536 --dtype f64 --gt 1 --batch 65536 --steps 6 --warmup 2 --no-secondary --no-cpu-baseline --in-flight 1 > $O/${TAG}_collect_f64_gt1.log 2>&1
+echo "[collect] pmc gt 65536 done"

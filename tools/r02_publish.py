@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Copies what tools/r02_collect.sh <tag> left under gpurun_out/ into profiles/ under the names DESIGN.md cites."""
+import glob, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+G, P = os.path.join(ROOT, 'gpurun_out'), os.path.join(ROOT, 'profiles')
+def cp(src, dst):
+    s = os.path.join(G, src)
+    if os.path.exists(s) and os.path.getsize(s) > 0:
+        shutil.copy(s, os.path.join(P, dst)); print('published', dst)
+    else:
+        print('MISSING', src)
+for k in ('bench_b4096', 'bench_b65536', 'bench_gt_sc1_b65536', 'bench_gt_sc3_b65536'):
+    cp(f'{tag}_{k}.json', f'r02_{k}.json')
+for k in ('inflight_sweep', 'f64_probe', 'f32_margin', 'closed_loop'):
+    cp(f'{tag}_{k}.txt', f'r02_{k}.txt')
+for k in ('f64_b4096', 'f64_b65536', 'f32_b4096', 'f32_gt1_b65536', 'f64_gt1_b65536'):
+    cp(f'{tag}_{k}/summary.json', f'r02_pmc_{k}.json')
+    st = glob.glob(os.path.join(G, f'{tag}_{k}', 'stats', '**', '*kernel_stats.csv'), recursive=True)
+    if st:
+        shutil.copy(st[0], os.path.join(P, f'r02_kernel_stats_{k}.csv')); print('published', f'r02_kernel_stats_{k}.csv')
+# the literal-mapping lines of the probe, on their own
+fp = os.path.join(G, f'{tag}_f64_probe.txt')
+if os.path.exists(fp):
+    lines = open(fp).read().splitlines()
+    keep = [l for l in lines if 'B=  4096' in l and ('dev=    0' in l or 'dev= 2048' in l) and l.startswith('f64')] + [l for l in lines if 'literal' in l]
+    open(os.path.join(P, 'r02_literal_mapping_b4096.txt'), 'w').write(
+        'f64 search pass at B = 4096: production (dev=0) vs the literal north_star mapping, one wave per (scenario, candidate)\n'
+        'trajectory with the horizon staged in LDS and a stage-parallel cost (dev=2048, search_literal_f64_kernel)\n' + '\n'.join(keep) + '\n')
+    print('published r02_literal_mapping_b4096.txt')
