@@ -276,7 +276,6 @@ def main():
         # independent), so the exchange of step t runs on its own stream under the search pass of step t+1,
         # double-buffered; the timed region ends with a device-wide synchronize, i.e. with every exchange complete.
         if exchange:
-            main_s = torch.cuda.current_stream(dev)
             comm = torch.cuda.Stream(dev)
             u0_buf = [torch.empty((Bm, 2), dtype=td, device=f'cuda:{dev}') for _ in range(2)]
             gathered = [torch.empty((Bm * world, 2), dtype=td, device=f'cuda:{dev}') for _ in range(2)]
@@ -287,23 +286,20 @@ def main():
         step_no = [0]
 
         def step():
-            if F > 1:       # step t on handle / stream t mod F; the inputs are read-only, every lane has its own outputs
-                q = step_no[0] % F
-                with torch.cuda.stream(lanes[q]):
-                    solvers[q].solve(*dargs, out=outs[q])
-                if not exchange:
-                    step_no[0] += 1
-                    return
-                main_s.wait_stream(lanes[q])
-            else:
-                q = 0
-                solver.solve(*dargs, out=out)
+            # step t on handle / stream t mod F; the inputs are read-only, every lane has its own outputs.  The staging
+            # copy of u*[:, :, 0] runs on the lane's own stream right behind the solve (so the lane's next solve cannot
+            # overwrite what is still being copied); the all-gather runs on the communication stream.
+            q = step_no[0] % F
+            lane = lanes[q] if F > 1 else torch.cuda.current_stream(dev)
+            i = step_no[0] & 1
+            step_no[0] += 1
+            with torch.cuda.stream(lane):
+                solvers[q].solve(*dargs, out=outs[q])
+                if exchange:
+                    lane.wait_event(ev_free[i])                # the exchange two steps back has released buffer i
+                    u0_buf[i].copy_(outs[q]['u'][:, :, 0])
+                    ev_ready[i].record(lane)
             if exchange:
-                i = step_no[0] & 1
-                step_no[0] += 1
-                main_s.wait_event(ev_free[i])                  # the exchange two steps back has released buffer i
-                u0_buf[i].copy_(outs[q]['u'][:, :, 0])
-                ev_ready[i].record(main_s)
                 with torch.cuda.stream(comm):
                     comm.wait_event(ev_ready[i])
                     dist.all_gather_into_tensor(gathered[i], u0_buf[i])
