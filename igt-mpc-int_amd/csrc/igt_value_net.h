@@ -476,6 +476,11 @@ __global__ __launch_bounds__(512) void value_mfma_f64_kernel(DevNet<double> net,
         // x_N = [s_tv, v_tv, e_tv, s_N - s_tv, v_N - v_tv, e_ego - e_tv]   (mpc.py:326-338); B operand: feature 4 s + g
         const double x0 = g == 0 ? s_tv : g == 1 ? v_tv : g == 2 ? e_tv : sN - s_tv;
         const double x1 = g == 0 ? vN - v_tv : g == 1 ? e_ego - e_tv : g == 2 ? 1.0 : 0.0;
+        // the second matrix is read through L2 at compile-time offsets from this pointer; it is made opaque per
+        // iteration so that the 256 fragment addresses are formed where they are used, not hoisted out of the loop
+        // (kept live they would spill ~600 registers)
+        const double* wg = WFg + lane;
+        asm volatile("" : "+v"(wg));
         f64x4 Ha[8], Hb[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -484,6 +489,7 @@ __global__ __launch_bounds__(512) void value_mfma_f64_kernel(DevNet<double> net,
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A1F[(t * 2 + 1) * 64 + lane], x1, acc, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) Ha[t][r] = tanh_d(acc[r]);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
@@ -494,22 +500,27 @@ __global__ __launch_bounds__(512) void value_mfma_f64_kernel(DevNet<double> net,
                 for (int r = 0; r < 4; ++r) acc[r] = BF[m * FRAGD_B + (t * 4 + r) * 4 + g];
 #pragma unroll
                 for (int ti = 0; ti < 8; ++ti) {
+                    // 4 A fragments at a time: without the fences the ILP scheduler hoists a whole layer's fragment reads
+                    // and spills hundreds of registers
                     double afr[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int idx = ((t * 8 + ti) * 4 + r) * 64 + lane;
-                        afr[r] = (m == 0) ? ldsd[idx] : WFg[(size_t)m * FRAGD_W + idx];
+                        const int idx = ((t * 8 + ti) * 4 + r) * 64;
+                        afr[r] = (m == 0) ? ldsd[idx + lane] : wg[(size_t)m * FRAGD_W + idx];
                     }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const double bop = (m == 0) ? Ha[ti][r] : Hb[ti][r];
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[r], bop, acc, 0, 0, 0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (m == 0) Hb[t][r] = tanh_d(acc[r]); else Ha[t][r] = tanh_d(acc[r]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         double v = 0.0;
