@@ -1238,10 +1238,10 @@ hipError_t prepare_value_kernels(int n_hidden_mats) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_mfma_f64_kernel<1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FRAGD_W * sizeof(double)));
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FRAGD_LDS * sizeof(double)));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&value_mfma_f64_kernel<2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FRAGD_W * sizeof(double)));
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FRAGD_LDS * sizeof(double)));
     if (e != hipSuccess) return e;
     const size_t lds_f = (size_t)frag_floats(n_hidden_mats) * sizeof(float);
     if (n_hidden_mats > 1)
@@ -1258,7 +1258,7 @@ template <>
 hipError_t launch_value<double>(const KP& P, int B, const DevNet<double>& net, const SolveArgs<double>& A,
                                 double* cost_all, uint32_t* viol_all, hipStream_t st) {
     if (!cost_all && !(P.dev & 1024)) {   // solve path: the compact list of feasible candidates on the f64 matrix cores
-        const size_t lds = (size_t)FRAGD_W * sizeof(double);
+        const size_t lds = (size_t)FRAGD_LDS * sizeof(double);
         if (net.n_hidden_mats > 1)
             hipLaunchKernelGGL(value_mfma_f64_kernel<2>, dim3(A.n_cu), dim3(512), lds, st, net, A.rec_count, A.rec_b, A.rec_sN,
                                A.rec_vN, A.rec_J, A.tv_sv, A.enc);

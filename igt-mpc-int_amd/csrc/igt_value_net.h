@@ -450,6 +450,10 @@ __device__ __forceinline__ double tanh_d(double x) {
     return fma(-2.0, q, 1.0);
 }
 
+// LDS image of the fragment block: the first hidden matrix, then the small fragments (layer 1, biases, output row)
+constexpr int FRAGD_LDS_SMALL = FRAGD_A1 + 2 * FRAGD_B + FRAGD_B;      // A1F | BF[0..1] | WOF
+constexpr int FRAGD_LDS = FRAGD_W + FRAGD_LDS_SMALL;                   // doubles (139 KB)
+
 template <int NM>
 __global__ __launch_bounds__(512) void value_mfma_f64_kernel(DevNet<double> net, const unsigned* __restrict__ rec_count,
                                                              const int32_t* __restrict__ rec_b,
@@ -457,11 +461,14 @@ __global__ __launch_bounds__(512) void value_mfma_f64_kernel(DevNet<double> net,
                                                              const double* __restrict__ rec_vN, double* __restrict__ rec_J,
                                                              const double* __restrict__ tv_sv, const double* __restrict__ enc) {
     extern __shared__ double ldsd[];
-    const double* __restrict__ A1F = net.fragd;
-    const double* __restrict__ WFg = A1F + FRAGD_A1;
-    const double* __restrict__ BF = WFg + NM * FRAGD_W;
-    const double* __restrict__ WOF = BF + NM * FRAGD_B;
+    const double* __restrict__ WFg = net.fragd + FRAGD_A1;
+    double* const A1F = ldsd + FRAGD_W;
+    double* const BF = A1F + FRAGD_A1;
+    double* const WOF = BF + 2 * FRAGD_B;
     for (int i = threadIdx.x; i < FRAGD_W; i += 512) ldsd[i] = WFg[i];
+    for (int i = threadIdx.x; i < FRAGD_A1; i += 512) A1F[i] = net.fragd[i];
+    for (int i = threadIdx.x; i < NM * FRAGD_B; i += 512) BF[i] = WFg[NM * FRAGD_W + i];
+    for (int i = threadIdx.x; i < FRAGD_B; i += 512) WOF[i] = WFg[NM * FRAGD_W + NM * FRAGD_B + i];
     __syncthreads();
     const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
     const unsigned count = *rec_count;
@@ -482,43 +489,53 @@ __global__ __launch_bounds__(512) void value_mfma_f64_kernel(DevNet<double> net,
         const double* wg = WFg + lane;
         asm volatile("" : "+v"(wg));
         f64x4 Ha[8], Hb[8];
+        // Two output tiles at a time: a dependent v_mfma_f64_16x16x4_f64 chain issues every ~214 cycles on gfx950, two
+        // interleaved chains every ~160 (tools/mfma64_microbench.hip), and a wave of the other SIMD slot fills the rest.
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A1F[(t * 2 + 0) * 64 + lane], x0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A1F[(t * 2 + 1) * 64 + lane], x1, acc, 0, 0, 0);
+        for (int t = 0; t < 8; t += 2) {
+            f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1F[(t * 2 + 0) * 64 + lane], x0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1F[(t * 2 + 2) * 64 + lane], x0, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1F[(t * 2 + 1) * 64 + lane], x1, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1F[(t * 2 + 3) * 64 + lane], x1, acc1, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Ha[t][r] = tanh_d(acc[r]);
+            for (int r = 0; r < 4; ++r) { Ha[t][r] = tanh_d(acc0[r]); Ha[t + 1][r] = tanh_d(acc1[r]); }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                f64x4 acc;
+            for (int t = 0; t < 8; t += 2) {
+                f64x4 acc0, acc1;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = BF[m * FRAGD_B + (t * 4 + r) * 4 + g];
+                for (int r = 0; r < 4; ++r) {
+                    acc0[r] = BF[m * FRAGD_B + (t * 4 + r) * 4 + g];
+                    acc1[r] = BF[m * FRAGD_B + ((t + 1) * 4 + r) * 4 + g];
+                }
 #pragma unroll
                 for (int ti = 0; ti < 8; ++ti) {
-                    // 4 A fragments at a time: without the fences the ILP scheduler hoists a whole layer's fragment reads
+                    // 8 A fragments at a time: without the fences the ILP scheduler hoists a whole layer's fragment reads
                     // and spills hundreds of registers
-                    double afr[4];
+                    double af0[4], af1[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int idx = ((t * 8 + ti) * 4 + r) * 64;
-                        afr[r] = (m == 0) ? ldsd[idx + lane] : wg[(size_t)m * FRAGD_W + idx];
+                        const int i0 = ((t * 8 + ti) * 4 + r) * 64, i1 = (((t + 1) * 8 + ti) * 4 + r) * 64;
+                        af0[r] = (m == 0) ? ldsd[i0 + lane] : wg[(size_t)m * FRAGD_W + i0];
+                        af1[r] = (m == 0) ? ldsd[i1 + lane] : wg[(size_t)m * FRAGD_W + i1];
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const double bop = (m == 0) ? Ha[ti][r] : Hb[ti][r];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[r], bop, acc, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[r], bop, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[r], bop, acc1, 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (m == 0) Hb[t][r] = tanh_d(acc[r]); else Ha[t][r] = tanh_d(acc[r]);
+                    if (m == 0) { Hb[t][r] = tanh_d(acc0[r]); Hb[t + 1][r] = tanh_d(acc1[r]); }
+                    else { Ha[t][r] = tanh_d(acc0[r]); Ha[t + 1][r] = tanh_d(acc1[r]); }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
