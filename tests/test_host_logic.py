@@ -197,3 +197,34 @@ def test_bench_refuses_a_multi_gpu_line_it_cannot_measure():
     assert r.returncode != 0 and 'refusing' in r.stderr and not r.stdout.strip()
     r = _run_bench('--gpus', '2', env_extra={'WORLD_SIZE': '4', 'RANK': '0'})      # launcher and flag disagree
     assert r.returncode != 0 and 'WORLD_SIZE=4' in r.stderr
+
+
+def test_curvature_from_callable_recovers_exact_breakpoints():
+    """Any callable K(s) of the reference's shape (evaluate.py:384-402 builds a casadi Function) is probed for
+    (b0, b1, Kv): grid + bisection to the last representable s -- the exact float64 numbers the callable compares."""
+    from igtmpc.vehicle import Curvature
+    from igtmpc import routes as R
+    for r in R.ROUTES:
+        b0, b1, kv = (float(q) for q in R.kparams(R.ROUTE_ID[r]))
+        K = (lambda b0, b1, kv: (lambda s: (kv if s >= b0 else 0.0) - (kv if s >= b1 else 0.0)))(b0, b1, kv)
+        got = Curvature.from_callable(K).kparams
+        assert got == ((b0, b1, kv) if kv != 0.0 else (float('inf'), float('inf'), 0.0)), r
+        assert Curvature.from_callable(K) is Curvature.from_callable(K)           # cached on the callable
+    with pytest.raises(ValueError):
+        Curvature.from_callable(lambda s: 0.1)
+    with pytest.raises(ValueError):
+        Curvature.from_callable(lambda s: 0.1 * (int(s) % 2))
+
+
+def test_bench_names_the_configuration_it_runs():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bm)
+    assert [bm.default_batch(n) for n in (1, 2, 4, 8)] == [4096, 4096, 4096, 32768]
+    assert 'configs[1]' in bm.workload_name(4096, 1, 0) and 'batch=4096' in bm.workload_name(4096, 1, 0)
+    assert 'configs[2]' in bm.workload_name(65536, 1, 0)
+    assert 'configs[3]' in bm.workload_name(32768, 8, 0) and '262144' in bm.workload_name(32768, 8, 0)
+    assert 'configs[4]' in bm.workload_name(65536, 1, 1)
+    assert 'custom' in bm.workload_name(12345, 1, 0) and 'configs' not in bm.workload_name(12345, 1, 0).split(':')[0].replace('custom batch', '')
+    assert len(bm.source_hash()) == 16
