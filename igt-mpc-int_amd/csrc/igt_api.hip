@@ -112,14 +112,15 @@ int validate(const igt_params& p, std::string& why) {
     if (p.cand_mode == IGT_CAND_LATTICE) {
         const int g = isqrt_exact(p.C);
         if (g < 2 || 64 % g) { why = "lattice candidates need C = G*G with G in {2,4,8,16,32,64}; use IGT_CAND_TABLE"; return -1; }
-    } else if (p.cand_mode == IGT_CAND_RAMP_HOLD) {
+    } else if (p.cand_mode == IGT_CAND_RAMP_HOLD || p.cand_mode == IGT_CAND_TRACK) {
         const int g = isqrt_exact(p.C);
         if (g < 4 || 64 % g) { why = "ramp-hold candidates need C = G*G with G in {4,8,16,32,64}"; return -1; }
     } else if (p.cand_mode != IGT_CAND_TABLE) {
         why = "unknown cand_mode"; return -1;
     }
     if (p.refine_iters < 0 || p.refine_iters > 4) { why = "refine_iters must be in [0, 4]"; return -1; }
-    if (p.refine_iters > 0 && p.cand_mode != IGT_CAND_RAMP_HOLD) { why = "refine_iters needs IGT_CAND_RAMP_HOLD"; return -1; }
+    if (p.refine_iters > 0 && p.cand_mode != IGT_CAND_RAMP_HOLD && p.cand_mode != IGT_CAND_TRACK) { why = "refine_iters needs IGT_CAND_RAMP_HOLD or IGT_CAND_TRACK"; return -1; }
+    if (p.cand_mode == IGT_CAND_TRACK && (!(p.track_ke >= 0) || !(p.track_span >= 0) || !(p.track_beta_lim > 0) || !(p.track_beta_lim < 1.5))) { why = "track_ke, track_span must be >= 0 and 0 < track_beta_lim < 1.5"; return -1; }
     if (p.cost_mode != IGT_COST_PROGRESS && p.cost_mode != IGT_COST_VALUE_NET) { why = "unknown cost_mode"; return -1; }
     if (!(p.v_min <= p.v_max) || !(p.a_min <= p.a_max) || !(p.df_max >= 0)) { why = "inconsistent limits"; return -1; }
     if (!(p.feas_tol >= 0)) { why = "feas_tol must be >= 0"; return -1; }
@@ -145,6 +146,7 @@ igt::KP make_kp(const igt_params& p, int F) {
     k.dmin2 = p.d_min * p.d_min;               // mpc.py:226
     k.w_u = p.w_u;
     k.tol = p.feas_tol;
+    k.trk_ke = p.track_ke; k.trk_span = p.track_span; k.trk_blim = p.track_beta_lim;
     // stage-offset polynomials: short form while h * (largest angular rate a candidate can reach) stays
     // small (igt_fast.h small_sincos2); v up to v_max + 2, |K| up to 0.25, sin(beta)/l_r <= 0.7/l_r
     const double vhi = std::fmax(std::fabs(p.v_min), std::fabs(p.v_max)) + 2.0;
@@ -211,8 +213,8 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     const igt_params& p = h->p;
     if (p.n_obs > 0 && !obs_xy) return fail(IGT_E_INVALID, "obs_xy is null but n_obs > 0");
     if (p.cand_mode == IGT_CAND_TABLE && !h->table_set) return fail(IGT_E_STATE, "candidate table not set");
-    if (u_ws && p.cand_mode != IGT_CAND_RAMP_HOLD)
-        return fail(IGT_E_INVALID, "a warm start needs IGT_CAND_RAMP_HOLD (the family whose targets are centred on it)");
+    if (u_ws && p.cand_mode != IGT_CAND_RAMP_HOLD && p.cand_mode != IGT_CAND_TRACK)
+        return fail(IGT_E_INVALID, "a warm start needs IGT_CAND_RAMP_HOLD or IGT_CAND_TRACK (the families whose targets are centred on it)");
     const bool value = p.cost_mode == IGT_COST_VALUE_NET;
     if (value) {
         if (!h->net_set) return fail(IGT_E_STATE, "value net not set (igt_set_value_net)");
@@ -380,8 +382,8 @@ int rollout_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T
     const igt_params& p = h->p;
     if (p.n_obs > 0 && !obs_xy) return fail(IGT_E_INVALID, "obs_xy is null but n_obs > 0");
     if (p.cand_mode == IGT_CAND_TABLE && !h->table_set) return fail(IGT_E_STATE, "candidate table not set");
-    if (u_ws && p.cand_mode != IGT_CAND_RAMP_HOLD)
-        return fail(IGT_E_INVALID, "a warm start needs IGT_CAND_RAMP_HOLD (the family whose targets are centred on it)");
+    if (u_ws && p.cand_mode != IGT_CAND_RAMP_HOLD && p.cand_mode != IGT_CAND_TRACK)
+        return fail(IGT_E_INVALID, "a warm start needs IGT_CAND_RAMP_HOLD or IGT_CAND_TRACK (the families whose targets are centred on it)");
     const bool value = p.cost_mode == IGT_COST_VALUE_NET;
     if (value) {
         if (!h->net_set) return fail(IGT_E_STATE, "value net not set (igt_set_value_net)");
@@ -614,6 +616,7 @@ int igt_params_default(igt_params* p) {
     p->w_u = 0.05;                                        /* mpc.py:362 */
     p->feas_tol = 1e-6;
     p->refine_iters = 0;
+    p->track_ke = 0.3; p->track_span = 0.1; p->track_beta_lim = 0.7;
     return IGT_OK;
 }
 

@@ -27,9 +27,10 @@ struct KP {  // kernel parameters (by value -> SGPRs)
     int dev;
     double dt, h, l_r, lr_ratio, v_min, v_max, a_min, a_max, df_max;
     double rate_a, rate_df, ey_lim, dmin2, w_u, tol;
+    double trk_ke, trk_span, trk_blim;      // IGT_CAND_TRACK: lateral gain [1/m], span of the slip-angle offsets, |beta| limit
 };
 
-enum { CAND_LATTICE = 0, CAND_TABLE = 1, CAND_RAMP_HOLD = 2 };
+enum { CAND_LATTICE = 0, CAND_TABLE = 1, CAND_RAMP_HOLD = 2, CAND_TRACK = 3 };
 enum { VIOL_BOX_V = 1, VIOL_BOX_U = 2, VIOL_RATE = 4, VIOL_EY = 8, VIOL_TERMINAL = 16,
        VIOL_COLLISION = 32, VIOL_NONFINITE = 64 };
 
@@ -44,6 +45,20 @@ struct Ctl {
     double a, df;        // last generated control
     double da, ddf;      // lattice increments  /  ramp-hold: offsets of the targets from the base sequence
 };
+// Tracking family (IGT_CAND_TRACK): the acceleration of candidate (i, j) is the ramp-hold one (offset i from the base
+// sequence); its STEERING is a state feedback evaluated inside the roll-out, so that every acceleration profile gets
+// the steering that belongs to where it actually is (an open-loop steering sequence is timed, not placed: a candidate
+// that brakes reaches the arc later but would steer at the same step).  With the slip angle beta = atan(r tan df):
+//     e_y' = v sin(beta + epsi)   ->   beta_cmd,k = clamp(-epsi_k - k_e e_y,k + off_j, +-beta_lim),
+//     df_cmd = atan(tan(beta_cmd) / r),   df_k = df_{k-1} + clamp(df_cmd - df_{k-1}, +-rate)   (mpc.py:301-312)
+// off_j = c_b + m(u_j) span_b are the G offsets (dense around 0; re-centred by refinement passes like the ramp-hold
+// ones).  The realised (a_k, df_k) are an ordinary control sequence: u_out, cost and verdicts are those of the roll-out.
+__device__ __forceinline__ double track_steer(const KP& P, double df_prev, double ey, double ep, double off) {
+    const double beta = clampd(-ep - P.trk_ke * ey + off, -P.trk_blim, P.trk_blim);
+    const double cmd = atan(tan(beta) / P.lr_ratio);
+    return clampd(df_prev + clampd(cmd - df_prev, -P.rate_df, P.rate_df), -P.df_max, P.df_max);
+}
+
 // base sequence of the ramp-hold targets at step k
 template <typename T>
 __device__ __forceinline__ void ramp_base(const T* __restrict__ ws, int N, int k, double a_prev, double df_prev, double& ba,
@@ -69,7 +84,7 @@ __device__ __forceinline__ void ctl_init(Ctl& c, const KP& P, int idx, double a_
     c.a = a_prev;
     c.df = df_prev;
     const int i = idx / P.G, j = idx - i * P.G;
-    if (P.cand_mode == CAND_RAMP_HOLD) {     // da / ddf hold the OFFSETS from the base sequence
+    if (P.cand_mode == CAND_RAMP_HOLD || P.cand_mode == CAND_TRACK) {     // da / ddf hold the OFFSETS (see above)
         c.da = cpar[0] + cand_m(i, P.G, P.refine_it == 0) * cpar[2];
         c.ddf = cpar[1] + cand_m(j, P.G, P.refine_it == 0) * cpar[3];
         return;
@@ -82,7 +97,7 @@ __device__ __forceinline__ void ctl_init(Ctl& c, const KP& P, int idx, double a_
 // advances to step k; returns violation bits for the input box / rate constraints
 template <typename T>
 __device__ __forceinline__ unsigned ctl_step(Ctl& c, const KP& P, int idx, int k, const double* __restrict__ table,
-                                             const T* __restrict__ ws, double a_prev, double df_prev) {
+                                             const T* __restrict__ ws, double a_prev, double df_prev, double ey, double ep) {
     unsigned v = 0;
     if (P.cand_mode == CAND_TABLE) {
         const double a = table[((size_t)idx * 2 + 0) * P.N + k];
@@ -97,6 +112,12 @@ __device__ __forceinline__ unsigned ctl_step(Ctl& c, const KP& P, int idx, int k
         const double ta = clampd(ba + c.da, P.a_min, P.a_max), tdf = clampd(bdf + c.ddf, -P.df_max, P.df_max);
         c.a = clampd(c.a + clampd(ta - c.a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
         c.df = clampd(c.df + clampd(tdf - c.df, -P.rate_df, P.rate_df), -P.df_max, P.df_max);
+    } else if (P.cand_mode == CAND_TRACK) {
+        double ba, bdf;
+        ramp_base<T>(ws, P.N, k, a_prev, df_prev, ba, bdf);
+        const double ta = clampd(ba + c.da, P.a_min, P.a_max);
+        c.a = clampd(c.a + clampd(ta - c.a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
+        c.df = track_steer(P, c.df, ey, ep, c.ddf);
     } else {
         c.a = clampd(c.a + c.da, P.a_min, P.a_max);
         c.df = clampd(c.df + c.ddf, -P.df_max, P.df_max);
@@ -331,12 +352,12 @@ __device__ __forceinline__ void rollout_pass(const KP& P, const Scenario<T>& S, 
         typename Stepper::Beta B[NC];
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
-            bk[q].viol |= ctl_step<T>(ctl[q], P, cidx[q], k, table, S.ws, S.a_prev, S.df_prev);
+            double cur[7];
+            stp.get(st[q], cur);
+            bk[q].viol |= ctl_step<T>(ctl[q], P, cidx[q], k, table, S.ws, S.a_prev, S.df_prev, cur[3], cur[4]);
             sink.ctrl(q, k, ctl[q].a, ctl[q].df);
             // control effort first, then the tracking terms of state k (mpc.py:361-364)
             bk[q].J = bk[q].J + P.w_u * (ctl[q].a * ctl[q].a + ctl[q].df * ctl[q].df);
-            double cur[7];
-            stp.get(st[q], cur);
             book_state(bk[q], P, k, cur, nullptr, false);
             if (k >= 1) bk[q].viol |= collision_viol<T>(P, k, cur[0], cur[1], S.obs);
             if (k == P.N - 1) bk[q].viol |= terminal_viol(P, cur[5], ctl[q].a, cinf);

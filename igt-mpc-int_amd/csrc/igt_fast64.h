@@ -319,8 +319,9 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
         const int i = cidx / P.G, j = cidx - i * P.G;
         da = -P.rate_a + (2 * P.rate_a) * (double)i / (double)(P.G - 1);
         ddf = -P.rate_df + (2 * P.rate_df) * (double)j / (double)(P.G - 1);
-    } else if (CAND == CAND_RAMP_HOLD) {
-        // da / ddf hold the OFFSETS of the targets from the base sequence here (igt_device.h cand_m, ramp_base)
+    } else if (CAND == CAND_RAMP_HOLD || CAND == CAND_TRACK) {
+        // da / ddf hold the OFFSETS of the targets from the base sequence here (igt_device.h cand_m, ramp_base);
+        // CAND_TRACK: ddf is the slip-angle offset of the steering feedback (track_steer)
         const int i = cidx / P.G, j = cidx - i * P.G;
         da = S.cpar[0] + cand_m(i, P.G, P.refine_it == 0) * S.cpar[2];
         ddf = S.cpar[1] + cand_m(j, P.G, P.refine_it == 0) * S.cpar[3];
@@ -342,6 +343,12 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
             const double ta = clampd(ba + da, P.a_min, P.a_max), tdf = clampd(bdf + ddf, -P.df_max, P.df_max);
             a = clampd(a + clampd(ta - a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
             df = clampd(df + clampd(tdf - df, -P.rate_df, P.rate_df), -P.df_max, P.df_max);
+        } else if (CAND == CAND_TRACK) {
+            double ba, bdf;
+            ramp_base<double>(S.ws, P.N, k, S.a_prev, S.df_prev, ba, bdf);
+            const double ta = clampd(ba + da, P.a_min, P.a_max);
+            a = clampd(a + clampd(ta - a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
+            df = track_steer(P, df, ey, ep, ddf);
         } else {
             const double an = table[((size_t)cidx * 2 + 0) * P.N + k];
             const double dn = table[((size_t)cidx * 2 + 1) * P.N + k];

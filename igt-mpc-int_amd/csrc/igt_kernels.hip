@@ -38,7 +38,7 @@ __device__ __forceinline__ void load_scenario(Scenario<T>& S, const KP& P, int b
         for (int i = 0; i < 4; ++i) S.cpar[i] = cpar.cpar[(size_t)b * 4 + i];
     } else {             // first pass: offsets centred on 0, span = what the rate limits reach over the horizon
         S.cpar[0] = 0.0; S.cpar[1] = 0.0;
-        S.cpar[2] = P.N * P.rate_a; S.cpar[3] = P.N * P.rate_df;
+        S.cpar[2] = P.N * P.rate_a; S.cpar[3] = P.cand_mode == CAND_TRACK ? P.trk_span : P.N * P.rate_df;
     }
 }
 
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void refine_targets_kernel(KP P, int B, int W,
     double ca, cd, sa, sd;
     if (first) {   // parameters of the first pass (load_scenario's defaults)
         ca = 0.0; cd = 0.0;
-        sa = P.N * P.rate_a; sd = P.N * P.rate_df;
+        sa = P.N * P.rate_a; sd = P.cand_mode == CAND_TRACK ? P.trk_span : P.N * P.rate_df;
     } else {
         ca = cpar[(size_t)b * 4 + 0]; cd = cpar[(size_t)b * 4 + 1]; sa = cpar[(size_t)b * 4 + 2]; sd = cpar[(size_t)b * 4 + 3];
     }
@@ -1160,10 +1160,12 @@ static hipError_t dispatch_search_fast(const KP& P, int B, const SolveArgs<float
     if (P.hi_order) {
         if (P.cand_mode == CAND_LATTICE) return launch_search_fast<CAND_LATTICE, true, VALUE>(P, B, A, st);
         if (P.cand_mode == CAND_RAMP_HOLD) return launch_search_fast<CAND_RAMP_HOLD, true, VALUE>(P, B, A, st);
+        if (P.cand_mode == CAND_TRACK) return launch_search_fast<CAND_TRACK, true, VALUE>(P, B, A, st);
         return launch_search_fast<CAND_TABLE, true, VALUE>(P, B, A, st);
     }
     if (P.cand_mode == CAND_LATTICE) return launch_search_fast<CAND_LATTICE, false, VALUE>(P, B, A, st);
     if (P.cand_mode == CAND_RAMP_HOLD) return launch_search_fast<CAND_RAMP_HOLD, false, VALUE>(P, B, A, st);
+    if (P.cand_mode == CAND_TRACK) return launch_search_fast<CAND_TRACK, false, VALUE>(P, B, A, st);
     return launch_search_fast<CAND_TABLE, false, VALUE>(P, B, A, st);
 }
 
@@ -1209,10 +1211,12 @@ static hipError_t dispatch_search64(const KP& P, int B, const SolveArgs<double>&
     if (P.hi_order) {
         if (P.cand_mode == CAND_LATTICE) return launch_search64<CAND_LATTICE, true, VALUE>(P, B, A, st);
         if (P.cand_mode == CAND_RAMP_HOLD) return launch_search64<CAND_RAMP_HOLD, true, VALUE>(P, B, A, st);
+        if (P.cand_mode == CAND_TRACK) return launch_search64<CAND_TRACK, true, VALUE>(P, B, A, st);
         return launch_search64<CAND_TABLE, true, VALUE>(P, B, A, st);
     }
     if (P.cand_mode == CAND_LATTICE) return launch_search64<CAND_LATTICE, false, VALUE>(P, B, A, st);
     if (P.cand_mode == CAND_RAMP_HOLD) return launch_search64<CAND_RAMP_HOLD, false, VALUE>(P, B, A, st);
+    if (P.cand_mode == CAND_TRACK) return launch_search64<CAND_TRACK, false, VALUE>(P, B, A, st);
     return launch_search64<CAND_TABLE, false, VALUE>(P, B, A, st);
 }
 template <>
@@ -1347,10 +1351,12 @@ hipError_t launch_emit<float>(const KP& P, int B, int W, const SolveArgs<float>&
     if (P.hi_order) {
         if (P.cand_mode == CAND_LATTICE) return launch_emit_fast<CAND_LATTICE, true>(P, B, W, A, st);
         if (P.cand_mode == CAND_RAMP_HOLD) return launch_emit_fast<CAND_RAMP_HOLD, true>(P, B, W, A, st);
+        if (P.cand_mode == CAND_TRACK) return launch_emit_fast<CAND_TRACK, true>(P, B, W, A, st);
         return launch_emit_fast<CAND_TABLE, true>(P, B, W, A, st);
     }
     if (P.cand_mode == CAND_LATTICE) return launch_emit_fast<CAND_LATTICE, false>(P, B, W, A, st);
     if (P.cand_mode == CAND_RAMP_HOLD) return launch_emit_fast<CAND_RAMP_HOLD, false>(P, B, W, A, st);
+    if (P.cand_mode == CAND_TRACK) return launch_emit_fast<CAND_TRACK, false>(P, B, W, A, st);
     return launch_emit_fast<CAND_TABLE, false>(P, B, W, A, st);
 }
 template <int CAND, bool HI>
@@ -1370,10 +1376,12 @@ hipError_t launch_emit<double>(const KP& P, int B, int W, const SolveArgs<double
     if (P.hi_order) {
         if (P.cand_mode == CAND_LATTICE) return launch_emit64<CAND_LATTICE, true>(P, B, W, A, st);
         if (P.cand_mode == CAND_RAMP_HOLD) return launch_emit64<CAND_RAMP_HOLD, true>(P, B, W, A, st);
+        if (P.cand_mode == CAND_TRACK) return launch_emit64<CAND_TRACK, true>(P, B, W, A, st);
         return launch_emit64<CAND_TABLE, true>(P, B, W, A, st);
     }
     if (P.cand_mode == CAND_LATTICE) return launch_emit64<CAND_LATTICE, false>(P, B, W, A, st);
     if (P.cand_mode == CAND_RAMP_HOLD) return launch_emit64<CAND_RAMP_HOLD, false>(P, B, W, A, st);
+    if (P.cand_mode == CAND_TRACK) return launch_emit64<CAND_TRACK, false>(P, B, W, A, st);
     return launch_emit64<CAND_TABLE, false>(P, B, W, A, st);
 }
 
@@ -1391,10 +1399,12 @@ hipError_t launch_rollout_all<float>(const KP& P, int B, const SolveArgs<float>&
     if (P.hi_order) {
         if (P.cand_mode == CAND_LATTICE) return launch_rollout_all_fast<CAND_LATTICE, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
         if (P.cand_mode == CAND_RAMP_HOLD) return launch_rollout_all_fast<CAND_RAMP_HOLD, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+        if (P.cand_mode == CAND_TRACK) return launch_rollout_all_fast<CAND_TRACK, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
         return launch_rollout_all_fast<CAND_TABLE, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
     }
     if (P.cand_mode == CAND_LATTICE) return launch_rollout_all_fast<CAND_LATTICE, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
     if (P.cand_mode == CAND_RAMP_HOLD) return launch_rollout_all_fast<CAND_RAMP_HOLD, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+    if (P.cand_mode == CAND_TRACK) return launch_rollout_all_fast<CAND_TRACK, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
     return launch_rollout_all_fast<CAND_TABLE, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
 }
 template <int CAND, bool HI>
@@ -1417,10 +1427,12 @@ hipError_t launch_rollout_all<double>(const KP& P, int B, const SolveArgs<double
     if (P.hi_order) {
         if (P.cand_mode == CAND_LATTICE) return launch_rollout_all64<CAND_LATTICE, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
         if (P.cand_mode == CAND_RAMP_HOLD) return launch_rollout_all64<CAND_RAMP_HOLD, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+        if (P.cand_mode == CAND_TRACK) return launch_rollout_all64<CAND_TRACK, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
         return launch_rollout_all64<CAND_TABLE, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
     }
     if (P.cand_mode == CAND_LATTICE) return launch_rollout_all64<CAND_LATTICE, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
     if (P.cand_mode == CAND_RAMP_HOLD) return launch_rollout_all64<CAND_RAMP_HOLD, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+    if (P.cand_mode == CAND_TRACK) return launch_rollout_all64<CAND_TRACK, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
     return launch_rollout_all64<CAND_TABLE, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
 }
 

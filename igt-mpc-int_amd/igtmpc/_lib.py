@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libigtmpc.so')
 
 IGT_MEM_DEVICE, IGT_MEM_HOST = 0, 1
-IGT_CAND_LATTICE, IGT_CAND_TABLE, IGT_CAND_RAMP_HOLD = 0, 1, 2
+IGT_CAND_LATTICE, IGT_CAND_TABLE, IGT_CAND_RAMP_HOLD, IGT_CAND_TRACK = 0, 1, 2, 3
 IGT_COST_PROGRESS, IGT_COST_VALUE_NET = 0, 1
 IGT_FLAG_ABS_HEADING = 1
 IGT_FLAG_WARM = 2
@@ -23,7 +23,8 @@ class igt_params(C.Structure):
                 ('v_min', C.c_double), ('v_max', C.c_double), ('a_min', C.c_double), ('a_max', C.c_double),
                 ('df_max', C.c_double), ('jerk_limit', C.c_double), ('steer_rate_limit', C.c_double),
                 ('ey_lim', C.c_double), ('d_min', C.c_double), ('w_u', C.c_double), ('feas_tol', C.c_double),
-                ('refine_iters', C.c_int32), ('reserved', C.c_int32)]
+                ('refine_iters', C.c_int32), ('reserved', C.c_int32),
+                ('track_ke', C.c_double), ('track_span', C.c_double), ('track_beta_lim', C.c_double)]
 
 
 # every symbol include/igtmpc.h declares: name -> (restype, argtypes)

@@ -74,13 +74,13 @@ def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=
         E = num_samples
         pairs = [R.SCENARIO_ROUTES[sc - 1][(e if rotation is None else rotation) % 4] for e in range(E)]
         x, rid = initial_states(rng, pairs)                             # x[E,M,7]
-    warm = bool(warm_start) and cand_mode == 'ramp_hold'
+    warm = bool(warm_start) and cand_mode in ('ramp_hold', 'track')
     kp = R.kparams(rid)                                                 # [E,M,3]
     absh = R.TABLES['abs_heading'][rid]
     flags = absh.astype(np.uint32).reshape(-1)
     u_prev = np.tile(np.array([0.0 if gt else 0.1, 0.0]), (E, M, 1))    # evaluate.py:419 (mpc) / 171 (gt_mpc)
     solver = BatchSolver(N=N, dt=dt, n_rk4=n_rk4, C=C, n_obs=M - 1, device=device, dtype=dtype, cand_mode=cand_mode,
-                         refine_iters=refine_iters if cand_mode == 'ramp_hold' else 0,
+                         refine_iters=refine_iters if cand_mode in ('ramp_hold', 'track') else 0,
                          cost_mode='value_net' if gt else 'progress', **({} if feas_tol is None else {'feas_tol': feas_tol}))
     if gt:
         solver.set_value_net(**value_net)

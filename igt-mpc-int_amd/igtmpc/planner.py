@@ -167,7 +167,7 @@ class MPC_Planner:
         flags = np.array([1 if self._abs_heading[self.ind] else 0], dtype=np.uint32)
         kp = np.array([self.K.kparams], dtype=self._dt)
         u_ws = None
-        if u_sol_prev is not None and self.cand_mode == 'ramp_hold':
+        if u_sol_prev is not None and self.cand_mode in ('ramp_hold', 'track'):
             u_ws = np.ascontiguousarray(np.asarray(u_sol_prev, dtype=self._dt).reshape(1, 2, self.N))
             flags = flags | np.uint32(IGT_FLAG_WARM)
         t0 = time.time()

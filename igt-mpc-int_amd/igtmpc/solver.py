@@ -33,7 +33,7 @@ class BatchSolver:
         L.check(self.lib.igt_params_default(ct.byref(p)))
         p.N, p.dt, p.n_rk4, p.C, p.n_obs = N, dt, n_rk4, C, n_obs
         p.cand_mode = {'lattice': L.IGT_CAND_LATTICE, 'table': L.IGT_CAND_TABLE,
-                       'ramp_hold': L.IGT_CAND_RAMP_HOLD}[cand_mode]
+                       'ramp_hold': L.IGT_CAND_RAMP_HOLD, 'track': L.IGT_CAND_TRACK}[cand_mode]
         p.cost_mode = {'progress': L.IGT_COST_PROGRESS, 'value_net': L.IGT_COST_VALUE_NET}[cost_mode]
         for k, v in limits.items():
             if not hasattr(p, k):

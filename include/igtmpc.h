@@ -51,10 +51,15 @@ enum { IGT_MEM_DEVICE = 0, IGT_MEM_HOST = 1 };
 enum {
     IGT_CAND_LATTICE = 0,  /* G x G lattice of constant per-step (da, ddf) increments */
     IGT_CAND_TABLE = 1,    /* explicit table U[C,2,N] shared by every scenario         */
-    IGT_CAND_RAMP_HOLD = 2 /* G x G: a and df track, at the rate limits, base sequence + one of G offsets each; the
+    IGT_CAND_RAMP_HOLD = 2,/* G x G: a and df track, at the rate limits, base sequence + one of G offsets each; the
                               base is u_prev held over the horizon or -- igt_solve_batch_ws_* -- the warm start (the
                               previous solution shifted by one step); offsets are dense around 0 (first pass) and, with
                               refine_iters > 0, re-centred on the previous pass's winner with its grid cell's spacing */
+    IGT_CAND_TRACK = 3     /* G x G: acceleration as IGT_CAND_RAMP_HOLD (offset i from the base sequence); STEERING is a
+                              state feedback evaluated inside the roll-out: beta_cmd = clamp(-epsi - track_ke * ey + off_j),
+                              df tracks atan(tan(beta_cmd) (l_f + l_r) / l_r) at the steering-rate limit.  Every
+                              acceleration profile thereby gets the steering that belongs to where it actually is;
+                              the realised (a_k, df_k) are returned as u_out like any other candidate's            */
 };
 
 /* cost (mpc.py:356-373) */
@@ -100,8 +105,11 @@ typedef struct igt_params {
     double d_min;            /* 2*ca_radius, mpc.py:45 */
     double w_u;              /* 0.05, mpc.py:362 */
     double feas_tol;         /* inequality verdicts are g <= feas_tol */
-    int32_t refine_iters;    /* IGT_CAND_RAMP_HOLD only: extra search passes around the winner (0..4) */
+    int32_t refine_iters;    /* IGT_CAND_RAMP_HOLD / IGT_CAND_TRACK: extra search passes around the winner (0..4) */
     int32_t reserved;
+    double track_ke;         /* IGT_CAND_TRACK: lateral-error gain of the steering feedback [1/m]          (0.3)  */
+    double track_span;       /* IGT_CAND_TRACK: the G slip-angle offsets span +-track_span [rad]            (0.1)  */
+    double track_beta_lim;   /* IGT_CAND_TRACK: |beta_cmd| limit [rad]                                      (0.7)  */
 } igt_params;
 
 /* Fills *p with the reference's numbers: N=20, dt=0.1, n_rk4=4, C=256, n_obs=1,
@@ -177,7 +185,7 @@ int igt_solve_batch_f64(igt_handle* h, int32_t B, const double* x0, const double
  * shifted previous plan is itself candidate (G/2, G/2).  The state part x_sol_prev has no counterpart (shooting states
  * are implied by the controls).
  *   u_ws [B,2,N]   rows are read only where flags[b] & IGT_FLAG_WARM; NULL = no warm start anywhere.
- * Needs cand_mode IGT_CAND_RAMP_HOLD when u_ws != NULL. */
+ * Needs cand_mode IGT_CAND_RAMP_HOLD or IGT_CAND_TRACK (acceleration base only) when u_ws != NULL. */
 int igt_solve_batch_ws_f32(igt_handle* h, int32_t B, const float* x0, const float* u_prev,
                            const float* kparams, const uint32_t* flags, const float* obs_xy,
                            const float* tv_sv, const float* enc, const float* u_ws, float* x_out,

@@ -98,14 +98,14 @@ def run_episode(x_init, routes, P, cinf, M_sim=30, cand_mode='lattice', C=256, r
                                         None if plan is None else plan[0], None if plan is None else plan[1])
             flags = np.array([O.FLAG_ABS_HEADING if routes[i] in ABS_HEADING_ROUTES else 0], dtype=np.uint32)
             u_ws = None
-            if warm_start and cand_mode == 'ramp_hold' and i in prev_idx:                  # evaluate.py:478-481
+            if warm_start and cand_mode in ('ramp_hold', 'track') and i in prev_idx:       # evaluate.py:478-481
                 xs_p, us_p = prev_sols[prev_idx.index(i)]
                 u_ws = augment_prev_sol(xs_p, us_p, kp[i], P)[1][None]
                 flags = flags | np.uint32(O.FLAG_WARM)
                 events['warm'] += 1
             args = (cur[i][None], prev_in[i][None], kp[i][None], flags, obs[None, None], A, b, P)
-            if cand_mode == 'ramp_hold':
-                r = O.solve_batch_refined(*args, C=C, refine_iters=refine_iters, u_ws=u_ws)[-1]
+            if cand_mode in ('ramp_hold', 'track'):
+                r = O.solve_batch_refined(*args, C=C, refine_iters=refine_iters, u_ws=u_ws, cand=cand_mode)[-1]
             else:
                 r = O.solve_batch(*args, C=C)
             if r['status'][0] == 0:                                                        # evaluate.py:484-510

@@ -591,3 +591,69 @@ def test_warm_started_ramp_hold_matches_oracle(igt, dtype, tol, eps):
     with igt.BatchSolver(dtype=dtype) as s2:
         with pytest.raises(igt.IgtError):
             s2.solve(*args, u_ws=u_ws)
+
+
+# ----------------------------------------------------------------------------- tracking candidates (state-feedback steering)
+@pytest.mark.parametrize('dtype,tol,eps', [('f64', 1e-9, 1e-9), ('f32', REL_TOL, 2e-5)])
+def test_tracking_candidates_match_oracle(igt, dtype, tol, eps):
+    """IGT_CAND_TRACK: ramp-hold accelerations, steering as a state feedback evaluated inside the roll-out
+    (beta_cmd = -epsi - k_e ey + offset_j, rate-limited).  The controls come out of the roll-out, so every candidate's
+    controls AND trajectory are compared with the oracle's interleaved generation; then the solve, with a warm start on
+    two thirds of the scenarios and one refinement pass; and the family must beat ramp-hold on its own cost."""
+    npdt = np.float64 if dtype == 'f64' else np.float32
+    B = 192
+    b = _batch(B, npdt)
+    f = lambda k: np.asarray(b[k], dtype=np.float64)
+    P0 = O.Params()
+    prev = O.candidates_lattice(f('u_prev'), P0)[np.arange(B), (np.arange(B) * 37) % 256]
+    u_ws = np.ascontiguousarray(O.shift_controls(prev).astype(npdt))
+    u_prev = np.ascontiguousarray(prev[:, :, 0].astype(npdt))
+    flags = b['flags'] | np.where(np.arange(B) % 3 != 0, 2, 0).astype(np.uint32)
+    args = (b['x0'], u_prev, b['kparams'], flags, b['obs_xy'])
+    with igt.BatchSolver(dtype=dtype, cand_mode='track') as s0:
+        P = oracle_params(s0)
+        assert (s0.params.track_ke, s0.params.track_span, s0.params.track_beta_lim) == (0.3, 0.1, 0.7)
+        s0.set_cinf(*_cinf())
+        all0 = s0.rollout_all(*[a[:48] for a in args], u_ws=u_ws[:48])
+        first = s0.solve(*args, u_ws=u_ws)
+    with igt.BatchSolver(dtype=dtype, cand_mode='track', refine_iters=1) as s1:
+        s1.set_cinf(*_cinf())
+        got = s1.solve(*args, u_ws=u_ws)
+    with igt.BatchSolver(dtype=dtype, cand_mode='ramp_hold') as s2:
+        s2.set_cinf(*_cinf())
+        rh = s2.solve(*args, u_ws=u_ws)
+    up = u_prev.astype(np.float64)
+    passes = O.solve_batch_refined(f('x0'), up, f('kparams'), flags, f('obs_xy'), *_cinf(), P, refine_iters=1,
+                                   u_ws=u_ws.astype(np.float64), cand='track')
+    r0 = passes[0]
+    kp = f('kparams')[:, None, :]
+    x0 = O.apply_flags(f('x0'), flags)[:, None, :]
+    bp = O.breakpoint_distance(x0, r0['U'], kp, P)
+    clear = bp[:48] > eps
+    # the steering depends on the rolled state: f64 agrees to rounding, f32 to the trajectory tolerance
+    assert rel_err(all0['U'][clear], r0['U'][:48][clear]).max() <= (1e-12 if dtype == 'f64' else REL_TOL)
+    assert rel_err(all0['X'], r0['X'][:48]).max(axis=(-1, -2))[clear].max() <= tol
+    # steering differs between the accelerations of one offset column (it is placed, not timed)
+    assert np.abs(r0['U'][:, 0 * 16 + 8, 1] - r0['U'][:, 15 * 16 + 8, 1]).max() > 1e-3
+    amb0 = ambiguous_mask(r0, P, eps, eps, eps, bp)
+    ok0 = ~amb0
+    assert ok0.mean() > 0.85
+    assert (first['argmin'][ok0] == r0['argmin'][ok0]).all() and (first['status'][ok0] == r0['status'][ok0]).all()
+    sol = ok0 & (r0['status'] == 0)
+    assert sol.sum() > 60
+    assert rel_err(first['x'][sol], r0['x'][sol]).max() <= tol
+    assert rel_err(first['u'][sol], r0['u'][sol]).max() <= max(tol, 1e-12)
+    assert rel_err(first['cost'][sol], r0['cost'][sol]).max() <= tol
+    edge = np.zeros(B, bool)
+    for r in passes:
+        edge |= ambiguous_mask(r, P, eps, eps, eps, O.breakpoint_distance(x0, r['U'], kp, P), ties=False)
+    ref = passes[-1]
+    tie = ~edge
+    assert tie.mean() > 0.8
+    assert (got['status'][tie] == ref['status'][tie]).all()
+    st = tie & (ref['status'] == 0)
+    assert rel_err(got['cost'][st], ref['cost'][st]).max() <= max(10 * tol, 1e-7)
+    # quality: solves more scenarios than ramp-hold and costs less where both solve
+    assert (first['status'] == 0).sum() >= (rh['status'] == 0).sum()
+    both = (first['status'] == 0) & (rh['status'] == 0)
+    assert first['cost'][both].mean() < rh['cost'][both].mean() - 0.05
