@@ -9,7 +9,8 @@ from igtmpc.evaluate import run_closed_loop
 import itertools
 dtype = sys.argv[1] if len(sys.argv) > 1 else 'f64'
 cfgs = [('lattice', 0, False, None), ('ramp_hold', 0, False, None), ('ramp_hold', 0, True, None), ('ramp_hold', 1, True, None),
-        ('ramp_hold', 0, True, 1e-3)]
+        ('ramp_hold', 0, True, 1e-3), ('track', 0, False, None), ('track', 0, True, None), ('track', 1, True, None),
+        ('track', 0, True, 1e-3)]
 tot = {}
 for (cm, ri, ws, ft), sc in itertools.product(cfgs, range(1, 9)):
     r = run_closed_loop(sc=sc, num_samples=16, N=20, cand_mode=cm, refine_iters=ri, warm_start=ws, dtype=dtype, feas_tol=ft)
