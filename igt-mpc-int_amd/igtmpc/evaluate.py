@@ -48,7 +48,7 @@ def initial_states(rng, route_pairs):
 
 
 def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=256, n_rk4=4, device=0,
-                    dtype='f32', rotation=None, cand_mode='ramp_hold', refine_iters=0, verbose=False,
+                    dtype='f64', rotation=None, cand_mode='track', refine_iters=0, verbose=False,
                     eval_mode='mpc', value_net=None, device_resident=False, warm_start=True, init=None,
                     terminal_set=True, feas_tol=None):
     """eval_mode 'mpc' (evaluate.py:370-639) or 'gt_mpc' (123-369: terminal value network in the cost; needs
@@ -253,6 +253,8 @@ def main():
     ap.add_argument('--net_prefix', default='', help="key prefix inside the npz, e.g. 'sc1_'")
     ap.add_argument('--verbose', action='store_true')
     ap.add_argument('--device_resident', action='store_true', help='keep all per-step arrays in HBM (torch tensors)')
+    ap.add_argument('--cand_mode', default='track', choices=['lattice', 'ramp_hold', 'track'])
+    ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
     a = ap.parse_args()
     net = None
     if a.eval_mode == 'gt_mpc':
@@ -265,7 +267,7 @@ def main():
             i += 1
         net = dict(layers=layers)
     r = run_closed_loop(sc=a.sc, num_samples=a.num_samples, N=a.N, C=a.C, verbose=a.verbose, eval_mode=a.eval_mode,
-                        value_net=net, device_resident=a.device_resident)
+                        value_net=net, device_resident=a.device_resident, cand_mode=a.cand_mode, dtype=a.dtype)
     print(json.dumps({'sc': a.sc, 'episodes': a.num_samples, 'routes': r['routes'][:4],
                       'infeasible_ratio_mean': r['infeasible_ratio'].mean(axis=0).tolist(),
                       'deadlock_rate': float(r['deadlock'].mean()),

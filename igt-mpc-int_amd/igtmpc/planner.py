@@ -61,7 +61,7 @@ class MPC_Planner:
     def __init__(self, N=10, dt=0.1, agents=None, goals=None, ca_radius=2.8, ref=None, road_dim=(10, 50),
                  routes=None, ds_right=None, index=None, num_rk4_steps=7, solver='ipopt', ca_type='circle',
                  nn_config_dir=None, use_NN_cost2go=False, weights=(1, 1, 1),
-                 C=256, device=0, dtype='f64', value_net=None, cand_mode='ramp_hold', refine_iters=0):
+                 C=256, device=0, dtype='f64', value_net=None, cand_mode='track', refine_iters=0):
         assert agents is not None, 'Agents are not defined'           # mpc.py:155
         assert index is not None                                      # mpc.py:80
         if ca_type != 'circle':

@@ -415,8 +415,18 @@ def test_mpc_planner_warm_start_sequence_matches_oracle():
     preds = pred.predict(agents, inputs, routes, refs)
     model = igtmpc.KinematicBicycleModelFrenet(2.235, 2.235, 2.0, 0.1, discretization='rk4', mode='numpy', num_rk4_steps=4)
     i = 0
+    dflt = igtmpc.MPC_Planner(N=N, dt=0.1, ca_radius=2.8, agents=agents, routes=routes, ref=refs, goals=None,
+                              road_dim=(11.4, 50), ds_right=8.6, index=i, num_rk4_steps=4)
+    assert dflt.cand_mode == 'track' and dflt._solver.dtype == 'f64'      # defaults: tracking candidates, reference precision
+    dflt.update_initial_condition(agents[i], inputs[i])
+    dflt.update_predictions(preds, raw_preds=preds)
+    xd, ud, okd = dflt.solve()
+    st0 = agents[i]['state']
+    rd = O.solve_batch_refined(np.array([st0.state7()]), np.array([[0.1, 0.0]]), np.array([dflt.K.kparams]), np.array([0], np.uint32),
+                               np.array([[[[p.x for p in preds[1]], [p.y for p in preds[1]]]]]), *dflt.C_inf, P, cand='track')[-1]
+    assert okd == (rd['status'][0] == 0) and (not okd or rel_err(xd, rd['x'][0]).max() < 1e-9)
     pl = igtmpc.MPC_Planner(N=N, dt=0.1, ca_radius=2.8, agents=agents, routes=routes, ref=refs, goals=None,
-                            road_dim=(11.4, 50), ds_right=8.6, index=i, num_rk4_steps=4)
+                            road_dim=(11.4, 50), ds_right=8.6, index=i, num_rk4_steps=4, cand_mode='ramp_hold')
     assert pl.cand_mode == 'ramp_hold' and pl._solver.dtype == 'f64'
     pl.update_initial_condition(agents[i], inputs[i])
     pl.update_predictions(preds, raw_preds=preds)

@@ -18,6 +18,9 @@ fam = {'lattice (SURVEY 8d v0)': O.solve_batch(b['x0'], b['u_prev'], b['kparams'
 passes = O.solve_batch_refined(b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy'], *cinf, P, refine_iters=2)
 fam['ramp-hold'] = passes[0]
 fam['ramp-hold + 2 refinements'] = passes[-1]
+tr = O.solve_batch_refined(b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy'], *cinf, P, refine_iters=2, cand='track')
+fam['tracking'] = tr[0]
+fam['tracking + 2 refinements'] = tr[-1]
 idx = [i for i in range(64) if all(f['status'][i] == 0 for f in fam.values())][:n]
 print(f'{len(idx)} scenarios solvable by every family; cost = mpc.py:356-373 (lower is better)')
 base = None
