@@ -1439,12 +1439,10 @@ hipError_t launch_rollout_all<double>(const KP& P, int B, const SolveArgs<double
 template <>
 hipError_t launch_frenet_step<float>(const KP& P, int n, const float* x, const float* u, const float* kparams,
                                      float* x_next, hipStream_t st) {
-    if (P.hi_order)
-        hipLaunchKernelGGL((frenet_step_fast_kernel<true>), dim3((n + 255) / 256), dim3(256), 0, st, P, n, x, u, kparams,
-                           x_next);
-    else
-        hipLaunchKernelGGL((frenet_step_fast_kernel<false>), dim3((n + 255) / 256), dim3(256), 0, st, P, n, x, u, kparams,
-                           x_next);
+    // always the long stage-offset polynomials: this entry has no verdicts, so a caller may step states far outside the
+    // planner's speed box (the predictor allows v up to 20 m/s), where the short forms would leave the 1e-5 envelope
+    (void)P.hi_order;
+    hipLaunchKernelGGL((frenet_step_fast_kernel<true>), dim3((n + 255) / 256), dim3(256), 0, st, P, n, x, u, kparams, x_next);
     return hipGetLastError();
 }
 template <>
