@@ -222,7 +222,9 @@ int igt_rollout_batch_ws_f64(igt_handle* h, int32_t B, const double* x0, const d
  * object the reference's driver calls directly for warm-start extension and for the
  * brake fallback (kinematic_bicycle_model_frenet.py:16-192 numpy branch; call sites
  * utils.py:358, evaluate.py:520).  Uses the handle's dt, n_rk4, l_r, l_f.
- *   x [n,7]   u [n,2] = (a, df)   kparams [n,3]   x_next [n,7] */
+ *   x [n,7]   u [n,2] = (a, df)   kparams [n,3]   x_next [n,7]
+ * _f64 follows the reference operation for operation (<= 1e-12 of the golden transitions).  _f32 uses the float
+ * arithmetic of the solver with its long stage-offset polynomials: within 1e-5*max(1,|ref|) for |v| <= 25 m/s. */
 int igt_frenet_step_f32(igt_handle* h, int32_t n, const float* x, const float* u, const float* kparams,
                         float* x_next, int mem, void* stream);
 int igt_frenet_step_f64(igt_handle* h, int32_t n, const double* x, const double* u, const double* kparams,

@@ -529,3 +529,23 @@ def test_c_abi_allgather_controls_single_rank():
         torch.cuda.synchronize()
         assert torch.equal(got2.nan_to_num(), want.nan_to_num())
         L.check(s.lib.igt_comm_destroy(s._h))
+
+
+def test_frenet_step_f32_outside_the_speed_box():
+    """igt_frenet_step_f32 has no verdicts: a caller may step states far outside the planner's speed box (the predictor
+    allows v up to 20 m/s).  It must stay within 1e-5 of the float64 step there too."""
+    import igtmpc
+    rng = np.random.default_rng(3)
+    n = 512
+    x = np.column_stack([rng.uniform(0, 50, n), rng.uniform(-20, 30, n), rng.uniform(5, 40, n), rng.uniform(-0.2, 0.2, n),
+                         rng.uniform(-0.2, 0.2, n), rng.uniform(15, 20, n), rng.uniform(-3, 3, n)])
+    u = np.column_stack([rng.uniform(-4, 3, n), rng.uniform(-0.6, 0.6, n)])
+    kp = np.tile(np.array([19.3, 19.3 + 8.6 * np.pi / 2, 1 / 8.6]), (n, 1))
+    x32, u32, kp32 = x.astype(np.float32), u.astype(np.float32), kp.astype(np.float32)
+    with igtmpc.BatchSolver(dtype='f32', N=1, C=64, n_obs=0) as s:
+        got = s.frenet_step(x32, u32, kp32)
+    ref = O.frenet_rk4_step(x32.astype(np.float64), u32[:, 0].astype(np.float64), u32[:, 1].astype(np.float64),
+                            kp32.astype(np.float64), O.Params())
+    far = np.minimum(np.abs(ref[:, 2] - kp[:, 0]), np.abs(ref[:, 2] - kp[:, 1])) > 2.5     # a step travels up to 2 m
+    far &= np.minimum(np.abs(x[:, 2] - kp[:, 0]), np.abs(x[:, 2] - kp[:, 1])) > 2.5
+    assert far.sum() > 100 and rel_err(got[far], ref[far]).max() < REL_TOL
