@@ -1128,10 +1128,10 @@ template <int CAND, bool HI, bool VALUE>
 static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>& A, hipStream_t st) {
     const int W = (P.C + 127) / 128;
     const size_t total = (size_t)B * W;
-    // persistent waves on per-XCD queues; 3 per SIMD once there are >= 16 units per wave slot (B >= 24 576 at C = 256,
-    // measured crossover), else 2 per SIMD
-    const bool big = total >= (size_t)A.n_cu * 12 * 16;
-    const bool o3 = (P.dev & 8) ? false : (P.dev & 32) ? true : big;
+    // persistent waves on per-XCD queues, 2 per SIMD.  The 3-per-SIMD build (168 VGPRs, a spill around each unit) was
+    // ahead on big batches in round 1; with the sub-step variants unrolled it spills 228 B/lane and is behind at every
+    // size but one (B = 32 768: +0.7 %) -- it stays selectable for A/B runs (IGT_DEV_FLAGS = 32)
+    const bool o3 = (P.dev & 32) != 0;
     const size_t slots = (size_t)A.n_cu * 4 * (o3 ? 3 : 2);
     const size_t grid = total < slots ? total : slots;
     const unsigned* order = nullptr;
@@ -1183,9 +1183,9 @@ static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A
         return hipGetLastError();
     }
     const size_t total = (size_t)B * W;
-    // 3 waves per SIMD from 16 units per wave slot upwards, else 2 (same rule as the float kernels)
-    const bool big = total >= (size_t)A.n_cu * 12 * 16;
-    const bool o3 = (P.dev & 8) ? false : (P.dev & 32) ? true : big;
+    // 2 waves per SIMD (232 VGPRs, no spill); the 3-per-SIMD build spills 244 B/lane and is 3-8 % behind at every batch
+    // size (IGT_DEV_FLAGS = 32 selects it for A/B runs)
+    const bool o3 = (P.dev & 32) != 0;
     const size_t slots = (size_t)A.n_cu * 4 * (o3 ? 3 : 2);
     const size_t grid = total < slots ? total : slots;
     const unsigned* order = nullptr;

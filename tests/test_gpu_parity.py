@@ -289,32 +289,37 @@ def test_bad_arguments_fail_loudly(igt):
             s.solve(*_args(b))          # table never set
 
 
-# ----------------------------------------------------------------------------- big batches: the other search variant
-@pytest.mark.parametrize('value_net', [False, True])
-def test_big_batch_variant_equals_small_batch_variant(igt, golden_dir, value_net):
-    """From 16 units per wave slot upwards (B >= 24 576 at C = 256) the solver launches the 3-waves-per-SIMD build of
-    the persistent search kernel on its per-XCD queues; below that the 2-waves-per-SIMD build.  The same scenarios,
-    solved in one ragged big batch and in small pieces, must come out bit for bit the same -- with the progress cost
-    and with the value network on the compact list (MFMA kernel, atomicMin winner)."""
+# ----------------------------------------------------------------------------- big batches / the other search build
+@pytest.mark.parametrize('dtype,value_net', [('f32', False), ('f32', True), ('f64', False)])
+def test_big_batch_and_other_build_equal_small_pieces(igt, golden_dir, monkeypatch, dtype, value_net):
+    """The same scenarios solved in one ragged big batch (queues in index order, no longest-first sort), in small pieces
+    (sorted queues, other queue make-up), and by the 3-waves-per-SIMD build of the persistent search kernel
+    (IGT_DEV_FLAGS = 32; a spilling build kept for A/B runs) must come out bit for bit the same -- with the progress
+    cost and with the value network on the compact list (MFMA kernel, atomicMin winner)."""
     B = 24576 + 5                                  # not a multiple of 8: the last block of 8 has holes
-    b = _batch(B, np.float32)
+    b = _batch(B, np.float32 if dtype == 'f32' else np.float64)
     kw = {}
     extra = []
     if value_net:
         layers = _nets(golden_dir)[3]
         kw = dict(cost_mode='value_net')
         extra = [b['tv_sv'], b['enc']]
-    with igt.BatchSolver(dtype='f32', **kw) as s:
+    with igt.BatchSolver(dtype=dtype, **kw) as s:
         s.set_cinf(*_cinf())
         if value_net:
             s.set_value_net(layers)
         big = s.solve(*_args(b), *extra)
         cuts = [0, 4096, 8192, 8192 + 1003, 12288, 20000, B]
         parts = [s.solve(*[np.ascontiguousarray(a[lo:hi]) for a in list(_args(b)) + extra]) for lo, hi in zip(cuts[:-1], cuts[1:])]
-    for k in ('x', 'u', 'argmin', 'status'):
+    monkeypatch.setenv('IGT_DEV_FLAGS', '32')
+    with igt.BatchSolver(dtype=dtype, **kw) as s3:
+        s3.set_cinf(*_cinf())
+        if value_net:
+            s3.set_value_net(layers)
+        other = s3.solve(*_args(b), *extra)
+    for k in ('x', 'u', 'argmin', 'status', 'cost'):
         assert np.array_equal(np.concatenate([q[k] for q in parts]), big[k], equal_nan=True), k
-    # the value-net winner is kept as an orderable FLOAT key: equal after rounding by construction
-    assert np.array_equal(np.concatenate([q['cost'] for q in parts]), big['cost'], equal_nan=True)
+        assert np.array_equal(other[k], big[k], equal_nan=True), k
     assert (big['status'] == 0).mean() > 0.5
 
 

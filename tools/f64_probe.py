@@ -50,7 +50,7 @@ if __name__ == '__main__':
         flags = [int(f) for f in sys.argv[1][8:].split(',')]
         for B in [int(a) for a in sys.argv[2:]] or [4096]:
             for f in flags:
-                run(B, f, iters=9)
+                run(B, f, iters=9, dtype=os.environ.get('IGT_PROBE_DTYPE', 'f64'))
         sys.exit(0)
     sizes = [int(a) for a in sys.argv[1:]] or [4096, 32768]
     for B in sizes:
