@@ -662,3 +662,29 @@ def test_tracking_candidates_match_oracle(igt, dtype, tol, eps):
     assert (first['status'] == 0).sum() >= (rh['status'] == 0).sum()
     both = (first['status'] == 0) & (rh['status'] == 0)
     assert first['cost'][both].mean() < rh['cost'][both].mean() - 0.05
+
+
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
+def test_exact_ties_across_slices_resolve_to_the_lowest_index(igt, dtype):
+    """Steering-ordered slices hold their columns from the centre outwards, so of EXACTLY tied candidates the lowest
+    index can sit in the LAST slice.  Construction: a vehicle at rest with v_max = 0 and no control-effort
+    weight -- only the 16 candidates that keep a = 0 are feasible, steering changes nothing, all 16 tie exactly; the
+    winner must be candidate (i = 8, j = 0) = 128, which the steering order puts into the last slice (a reduction that
+    trusted the slice order would return (8, 8) = 136)."""
+    npdt = np.float64 if dtype == 'f64' else np.float32
+    B = 96
+    b = _batch(B, npdt)
+    b['x0'][:, 5] = 0.0
+    b['u_prev'][:, 0] = 0.0
+    f = lambda k: np.asarray(b[k], dtype=np.float64)
+    none = np.zeros((B, 0, 2, 21), npdt)
+    with igt.BatchSolver(dtype=dtype, cand_mode='ramp_hold', n_obs=0, v_max=0.0, w_u=0.0) as s:
+        P = oracle_params(s)
+        got = s.solve(b['x0'], b['u_prev'], b['kparams'], b['flags'], none)
+        allc = s.rollout_all(b['x0'][:8], b['u_prev'][:8], b['kparams'][:8], b['flags'][:8], none[:8], want_X=False, want_U=False)
+    ref = O.solve_batch_refined(f('x0'), f('u_prev'), f('kparams'), b['flags'], none.astype(np.float64), None, None, P)[0]
+    assert (ref['feas'].sum(axis=1) == 16).all() and (ref['argmin'] == 128).all()
+    assert all(len(np.unique(ref['J'][i, ref['feas'][i]])) == 1 for i in range(B)), 'the 16 feasible candidates must tie exactly'
+    assert ((allc['viol'] == 0).sum(axis=1) == 16).all()
+    assert all(len(np.unique(allc['cost'][i, allc['viol'][i] == 0])) == 1 for i in range(8))
+    assert (got['status'] == 0).all() and (got['argmin'] == 128).all()
