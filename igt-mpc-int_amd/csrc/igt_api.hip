@@ -351,7 +351,7 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     HIPCHK(igt::launch_emit<T>(kp, B, (int)W, A, st));
     if (h->prof) { HIPCHK(hipEventRecord(h->ev[2], st)); h->ev_recorded = true; }
 
-    if ((h->kp.dev & 256) && sizeof(T) == 4) {      // developer trace -> $IGT_DEV_TRACE (binary u64[units][4])
+    if (h->kp.dev & 256) {      // developer trace -> $IGT_DEV_TRACE (binary u64[units][4])
         if (const char* path = std::getenv("IGT_DEV_TRACE")) {
             HIPCHK(hipStreamSynchronize(st));
             const size_t n = (size_t)((B + 7) / 8) * 8 * Wk * 4;

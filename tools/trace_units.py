@@ -12,9 +12,10 @@ os.environ['IGT_DEV_TRACE'] = path
 import torch
 from igtmpc import BatchSolver
 from igtmpc.scenarios import make_batch
-b = make_batch(B, dtype=np.float32)
+DT = os.environ.get('IGT_PROBE_DTYPE', 'f64')
+b = make_batch(B, dtype=np.float32 if DT == 'f32' else np.float64)
 args = [torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda() for a in (b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy'])]
-with BatchSolver(dtype='f32') as s:
+with BatchSolver(dtype=DT) as s:
     for _ in range(3):
         s.solve(*args)
     torch.cuda.synchronize()
@@ -35,5 +36,10 @@ q = (tr[:, 2] % 8).astype(int)
 for qq in range(8):
     m = q == qq
     print(f'  queue {qq}: units {m.sum()}  first start {t0[m].min():.1f}  last start {t0[m].max():.1f}  last end {t1[m].max():.1f}  sum of durations {dur[m].sum()/1e3:.2f} ms  mean dur slice0 {dur[m & (p == 0)].mean():.1f} slice1 {dur[m & (p == 1)].mean():.1f}')
+# how good is the longest-first order?  duration vs position in the queue
+order = np.argsort(t0)
+k = len(order) // 10
+print('  mean unit duration by start-time decile:', [round(float(dur[order[i * k:(i + 1) * k]].mean()), 1) for i in range(10)])
+print('  p95 unit duration by start-time decile: ', [round(float(np.quantile(dur[order[i * k:(i + 1) * k]], .95)), 1) for i in range(10)])
 late = np.argsort(-t1)[:8]
 print('  last finishers: ' + ', '.join(f'(start {t0[i]:.0f} dur {dur[i]:.0f} slice {p[i]})' for i in late))
