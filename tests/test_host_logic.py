@@ -229,3 +229,20 @@ def test_bench_names_the_configuration_it_runs():
     assert 'configs[4]' in bm.workload_name(65536, 1, 1)
     assert 'custom' in bm.workload_name(12345, 1, 0) and 'configs' not in bm.workload_name(12345, 1, 0).split(':')[0].replace('custom batch', '')
     assert len(bm.source_hash()) == 16
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/igtmpc.h is the drop-in boundary: it must compile as C99 (and C++) on its own -- plain pointers and sizes,
+    no torch / HIP types in the signatures."""
+    import shutil
+    import subprocess
+    if not shutil.which('gcc'):
+        pytest.skip('no gcc')
+    src = tmp_path / 'hdr.c'
+    src.write_text('#include "igtmpc.h"\nint main(void) { igt_params p; return (int)sizeof(p) == 0; }\n')
+    inc = os.path.join(ROOT, 'include')
+    for cmd in (['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-fsyntax-only'], ['g++', '-std=c++11', '-x', 'c++', '-fsyntax-only']):
+        r = subprocess.run(cmd + ['-I', inc, str(src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    hdr = open(os.path.join(inc, 'igtmpc.h')).read()
+    assert re.findall(r'#include\s*[<"]([^>"]+)', hdr) == ['stdint.h']          # nothing but <stdint.h> is pulled in
