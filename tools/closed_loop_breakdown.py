@@ -5,7 +5,7 @@ the solve returned no candidate and the brake fallback was applied (evaluate.py:
             |ey| > ey_lim (constraints that include the current state, mpc.py:223-226 / 296-299)
   cascade   follows an infeasible step while still braking (u_prev.a = -4: no candidate keeps v >= 0 over the horizon)
   first     the step that started a cascade
-    python tools/closed_loop_breakdown.py [cand_mode] [N]"""
+    python tools/closed_loop_breakdown.py [cand_mode] [N] [C] [refine_iters]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'igt-mpc-int_amd'))
@@ -13,9 +13,11 @@ import numpy as np
 from igtmpc.evaluate import run_closed_loop
 cand = sys.argv[1] if len(sys.argv) > 1 else 'track'
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+C = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+RI = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 tot = dict(steps=0, infeasible=0, stopped=0, gridlock=0, stranded=0, cascade=0, first=0)
 for sc in range(1, 9):
-    r = run_closed_loop(sc=sc, num_samples=16, N=N, cand_mode=cand, dtype='f64')
+    r = run_closed_loop(sc=sc, num_samples=16, N=N, cand_mode=cand, dtype='f64', C=C, refine_iters=RI)
     x, u = r['x_data'], r['u_data']                 # [E, 14, T+1], [E, 4, T]
     E, _, T = u.shape
     for m in range(2):
@@ -42,7 +44,7 @@ for sc in range(1, 9):
         tot['gridlock'] += int((stopped & (d < 5.6)).sum()); tot['stranded'] += int((stopped & (np.abs(ey) > 0.2)).sum())
     chk = r['infeasible_ratio'].sum() * T
     print(f'sc {sc}: driver-counted infeasible agent-steps {chk:.0f}', flush=True)
-print(f'cand={cand} N={N}: {tot}')
+print(f'cand={cand} N={N} C={C} refine={RI}: {tot}')
 i = max(tot['infeasible'], 1)
 print(f"share of infeasible agent-steps: first {tot['first'] / i:.3f}  cascade {tot['cascade'] / i:.3f}  stopped {tot['stopped'] / i:.3f} "
       f"(gridlock within d_min {tot['gridlock'] / i:.3f}, stranded outside the lane {tot['stranded'] / i:.3f});  "
