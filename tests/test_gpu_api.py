@@ -549,3 +549,32 @@ def test_frenet_step_f32_outside_the_speed_box():
     far = np.minimum(np.abs(ref[:, 2] - kp[:, 0]), np.abs(ref[:, 2] - kp[:, 1])) > 2.5     # a step travels up to 2 m
     far &= np.minimum(np.abs(x[:, 2] - kp[:, 0]), np.abs(x[:, 2] - kp[:, 1])) > 2.5
     assert far.sum() > 100 and rel_err(got[far], ref[far]).max() < REL_TOL
+
+
+def test_plain_c_caller_gets_what_python_gets(tmp_path):
+    """examples/c_caller.c (C99, host buffers, igt_solve_batch_f64 through include/igtmpc.h alone) on its built-in batch
+    of 256 vehicles on route '12': the same problems through the Python face must give the same winner, cost and first
+    control as the C program prints."""
+    import re
+    import subprocess
+    import igtmpc
+    from test_host_logic import _build_c_caller
+    exe = _build_c_caller(tmp_path / 'c_caller')
+    r = subprocess.run([str(exe), '256'], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    m = re.match(r'solved (\d+) of 256; scenario (\d+): candidate (\d+), cost (\S+), applies a = (\S+) df = (\S+), s_N = (\S+)', r.stdout)
+    assert m, r.stdout
+    solved, first, cand, cost, a0, df0, sN = int(m[1]), int(m[2]), int(m[3]), float(m[4]), float(m[5]), float(m[6]), float(m[7])
+    B, N = 256, 20
+    b = np.arange(B)
+    s = 5.0 + 30.0 * b / B
+    v = 1.0 + 3.0 * ((b * 7) % B) / B
+    x0 = np.column_stack([s, np.full(B, 2.8), s, np.full(B, 0.01), np.full(B, -0.005), v, np.zeros(B)])
+    kp = np.tile([19.3, 19.3 + 8.6 * np.arccos(-1.0) / 2, 1.0 / 8.6], (B, 1))
+    obs = np.full((B, 1, 2, N + 1), -20.0)
+    with igtmpc.BatchSolver(dtype='f64') as sv:
+        out = sv.solve(x0, np.tile([0.1, 0.0], (B, 1)), kp, np.zeros(B, np.uint32), obs)
+    assert int((out['status'] == 0).sum()) == solved > 100
+    assert int(np.nonzero(out['status'] == 0)[0][0]) == first and int(out['argmin'][first]) == cand
+    assert abs(out['cost'][first] - cost) < 1e-5 and abs(out['u'][first, 0, 0] - a0) < 1e-4 and abs(out['u'][first, 1, 0] - df0) < 1e-4
+    assert abs(out['x'][first, 2, N] - sN) < 1e-4

@@ -246,3 +246,24 @@ def test_public_header_is_plain_c(tmp_path):
         assert r.returncode == 0, r.stderr
     hdr = open(os.path.join(inc, 'igtmpc.h')).read()
     assert re.findall(r'#include\s*[<"]([^>"]+)', hdr) == ['stdint.h']          # nothing but <stdint.h> is pulled in
+
+
+def _build_c_caller(out):
+    import shutil
+    import subprocess
+    if not shutil.which('gcc') or not os.path.exists('/opt/rocm/lib/libamdhip64.so'):
+        pytest.skip('needs gcc and the ROCm runtime library')
+    libdir = os.path.join(ROOT, 'igt-mpc-int_amd', 'igtmpc')
+    cmd = ['gcc', '-std=c99', '-O2', '-Wall', '-Wextra', '-Werror', '-I', os.path.join(ROOT, 'include'),
+           os.path.join(ROOT, 'examples', 'c_caller.c'), '-o', str(out), '-L', libdir, '-ligtmpc', f'-Wl,-rpath,{libdir}',
+           '-L/opt/rocm/lib', '-lamdhip64', '-lm']
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return out
+
+
+def test_plain_c_program_links_against_the_abi(tmp_path):
+    """examples/c_caller.c -- a C99 program with no Python and no torch -- compiles and links against libigtmpc.so
+    through include/igtmpc.h alone (it is run on the GPU box by tests/test_gpu_api.py)."""
+    exe = _build_c_caller(tmp_path / 'c_caller')
+    assert os.path.getsize(exe) > 0
