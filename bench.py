@@ -381,6 +381,9 @@ def main():
         if valu_insts:
             valu['achieved'] = valu_insts * VALU_ISSUE_CYCLES / (SIMDS * search_ms * 1e-3 * clk_ghz * 1e9)
             valu['frac'] = valu['achieved']
+            # the same instruction count against the whole pipelined step (what `value` is made of): the search kernel's
+            # drain tail and the emit pass are overlapped by the next steps' search passes
+            valu['frac_of_whole_step'] = valu_insts * VALU_ISSUE_CYCLES / (SIMDS * head['ms_per_step'] * 1e-3 * clk_ghz * 1e9)
         arith = {'f64': 'float64 throughout (stage derivatives, state, cost, verdicts)',
                  'f32': 'float32 stage derivatives + float64 state accumulators, cost and verdicts'}
         line = {
