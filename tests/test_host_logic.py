@@ -267,3 +267,28 @@ def test_plain_c_program_links_against_the_abi(tmp_path):
     through include/igtmpc.h alone (it is run on the GPU box by tests/test_gpu_api.py)."""
     exe = _build_c_caller(tmp_path / 'c_caller')
     assert os.path.getsize(exe) > 0
+
+
+def test_design_cites_profiles_that_exist_and_belong_together():
+    """DESIGN.md section 7 promises that every number comes from a file under profiles/ made at one kernel-source hash:
+    every cited file exists, and every PMC summary of the round carries the hash DESIGN.md names."""
+    import glob
+    import warnings
+    text = open(os.path.join(ROOT, 'DESIGN.md')).read() + open(os.path.join(ROOT, 'README.md')).read()
+    cited = set(re.findall(r'`(profiles/[A-Za-z0-9_./-]+\.(?:json|csv|txt))`', text))
+    assert len(cited) >= 15, cited
+    missing = [c for c in cited if not os.path.exists(os.path.join(ROOT, c))]
+    assert not missing, missing
+    m = re.search(r'kernel-source hash `([0-9a-f]{16})`', text)
+    assert m, 'DESIGN.md must name the kernel-source hash of its profiles'
+    pm = glob.glob(os.path.join(ROOT, 'profiles', 'r02_pmc_*.json'))
+    assert len(pm) >= 5
+    for f in pm:
+        assert json.load(open(f))['source_hash'] == m.group(1), f
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod2', os.path.join(ROOT, 'bench.py'))
+    bm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bm)
+    if bm.source_hash() != m.group(1):      # kernels changed since the profiles were collected: bench.py prints null PMC fields
+        warnings.warn(f'profiles/ were collected at {m.group(1)}, the kernel sources are now {bm.source_hash()}: '
+                      f're-run tools/r02_collect.sh + tools/r02_publish.py')
