@@ -120,7 +120,7 @@ int validate(const igt_params& p, std::string& why) {
     }
     if (p.refine_iters < 0 || p.refine_iters > 4) { why = "refine_iters must be in [0, 4]"; return -1; }
     if (p.refine_iters > 0 && p.cand_mode != IGT_CAND_RAMP_HOLD && p.cand_mode != IGT_CAND_TRACK) { why = "refine_iters needs IGT_CAND_RAMP_HOLD or IGT_CAND_TRACK"; return -1; }
-    if (p.cand_mode == IGT_CAND_TRACK && (!(p.track_ke >= 0) || !(p.track_span >= 0) || !(p.track_beta_lim > 0) || !(p.track_beta_lim < 1.5))) { why = "track_ke, track_span must be >= 0 and 0 < track_beta_lim < 1.5"; return -1; }
+    if (p.cand_mode == IGT_CAND_TRACK && (!(p.track_ke >= 0) || !(p.track_span >= 0) || !(p.track_beta_lim > 0) || !(p.track_beta_lim < 1.5) || !(p.track_env >= 0) || !(p.track_env < 1e6))) { why = "track_ke, track_span, track_env must be >= 0 (and finite) and 0 < track_beta_lim < 1.5"; return -1; }
     if (p.cost_mode != IGT_COST_PROGRESS && p.cost_mode != IGT_COST_VALUE_NET) { why = "unknown cost_mode"; return -1; }
     if (!(p.v_min <= p.v_max) || !(p.a_min <= p.a_max) || !(p.df_max >= 0)) { why = "inconsistent limits"; return -1; }
     if (!(p.feas_tol >= 0)) { why = "feas_tol must be >= 0"; return -1; }
@@ -147,6 +147,9 @@ igt::KP make_kp(const igt_params& p, int F) {
     k.w_u = p.w_u;
     k.tol = p.feas_tol;
     k.trk_ke = p.track_ke; k.trk_span = p.track_span; k.trk_blim = p.track_beta_lim;
+    // slope of the acceleration envelope (igt_device.h track_accel_target); products and one quotient only, so the
+    // oracle's track_env_slope() gives the same bits
+    k.trk_env = (p.track_env > 0 && p.w_u > 0) ? p.track_env * p.dt * p.dt / (2 * p.w_u) : (double)INFINITY;
     // stage-offset polynomials: short form while h * (largest angular rate a candidate can reach) stays
     // small (igt_fast.h small_sincos2); v up to v_max + 2, |K| up to 0.25, sin(beta)/l_r <= 0.7/l_r
     const double vhi = std::fmax(std::fabs(p.v_min), std::fabs(p.v_max)) + 2.0;
@@ -616,7 +619,7 @@ int igt_params_default(igt_params* p) {
     p->w_u = 0.05;                                        /* mpc.py:362 */
     p->feas_tol = 1e-6;
     p->refine_iters = 0;
-    p->track_ke = 0.3; p->track_span = 0.1; p->track_beta_lim = 0.7;
+    p->track_ke = 0.3; p->track_span = 0.1; p->track_beta_lim = 0.7; p->track_env = 1.0;
     return IGT_OK;
 }
 

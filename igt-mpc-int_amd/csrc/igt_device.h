@@ -28,6 +28,7 @@ struct KP {  // kernel parameters (by value -> SGPRs)
     double dt, h, l_r, lr_ratio, v_min, v_max, a_min, a_max, df_max;
     double rate_a, rate_df, ey_lim, dmin2, w_u, tol;
     double trk_ke, trk_span, trk_blim;      // IGT_CAND_TRACK: lateral gain [1/m], span of the slip-angle offsets, |beta| limit
+    double trk_env;                         // IGT_CAND_TRACK: slope of the acceleration envelope (+inf = none), track_accel_target
 };
 
 enum { CAND_LATTICE = 0, CAND_TABLE = 1, CAND_RAMP_HOLD = 2, CAND_TRACK = 3 };
@@ -57,6 +58,15 @@ __device__ __forceinline__ double track_steer(const KP& P, double df_prev, doubl
     const double beta = clampd(-ep - P.trk_ke * ey + off, -P.trk_blim, P.trk_blim);
     const double cmd = atan(tan(beta) / P.lr_ratio);
     return clampd(df_prev + clampd(cmd - df_prev, -P.rate_df, P.rate_df), -P.df_max, P.df_max);
+}
+
+// Acceleration target of the tracking family at step k.  One more unit of a_k buys dt (T - t_k - dt/2) of progress
+// (the -(s_N - s_0) term of the cost, mpc.py:372) and costs 2 w_u a_k (mpc.py:362): no unconstrained optimum asks for
+// more than E_k = dt^2 (N - k - 1/2) / (2 w_u), so the candidates' targets stay under that envelope -- a candidate
+// with a large offset ramps up at the jerk limit until it meets E_k and follows it down, which is the shape the
+// NLP's optimum has (tools/nlp_gap.py).  trk_env = track_env dt^2 / (2 w_u) (host, igt_api.hip), +inf when off.
+__device__ __forceinline__ double track_accel_target(const KP& P, int k, double base, double off) {
+    return clampd(fmin(base + off, P.trk_env * ((double)(P.N - k) - 0.5)), P.a_min, P.a_max);
 }
 
 // base sequence of the ramp-hold targets at step k
@@ -115,7 +125,7 @@ __device__ __forceinline__ unsigned ctl_step(Ctl& c, const KP& P, int idx, int k
     } else if (P.cand_mode == CAND_TRACK) {
         double ba, bdf;
         ramp_base<T>(ws, P.N, k, a_prev, df_prev, ba, bdf);
-        const double ta = clampd(ba + c.da, P.a_min, P.a_max);
+        const double ta = track_accel_target(P, k, ba, c.da);
         c.a = clampd(c.a + clampd(ta - c.a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
         c.df = track_steer(P, c.df, ey, ep, c.ddf);
     } else {

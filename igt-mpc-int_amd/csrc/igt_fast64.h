@@ -360,7 +360,7 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
         } else if (CAND == CAND_TRACK) {
             double ba, bdf;
             ramp_base<double>(S.ws, P.N, k, S.a_prev, S.df_prev, ba, bdf);
-            const double ta = clampd(ba + da, P.a_min, P.a_max);
+            const double ta = track_accel_target(P, k, ba, da);
             a = clampd(a + clampd(ta - a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
             df = track_steer(P, df, ey, ep, ddf);
         } else {

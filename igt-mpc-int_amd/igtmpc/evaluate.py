@@ -50,7 +50,7 @@ def initial_states(rng, route_pairs):
 def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=256, n_rk4=4, device=0,
                     dtype='f64', rotation=None, cand_mode='track', refine_iters=0, verbose=False,
                     eval_mode='mpc', value_net=None, device_resident=False, warm_start=True, init=None,
-                    terminal_set=True, feas_tol=None):
+                    terminal_set=True, feas_tol=None, limits=None):
     """eval_mode 'mpc' (evaluate.py:370-639) or 'gt_mpc' (123-369: terminal value network in the cost; needs
     value_net = dict(layers=[(W,b),...][, Wn, mu_f, sigma_t, mu_t]) -- the reference's normalisation statistics are
     not shipped, identity by default).  device_resident=True keeps every per-step array in HBM (torch tensors;
@@ -59,7 +59,8 @@ def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=
     shifted by one step (evaluate.py:478-481, utils.py:354-363 augment_prev_sol) instead of on u_prev held.
     init = (x[E,M,7], route_pairs[E]) overrides the sampled initial states; terminal_set=False drops the C_inf
     constraint (mpc.py:177-180) -- a test switch.  feas_tol: inequality tolerance of the verdicts (default: the
-    library's 1e-6; IPOPT's constr_viol_tol is 1e-3, mpc.py:135)."""
+    library's 1e-6; IPOPT's constr_viol_tol is 1e-3, mpc.py:135); limits: further igt_params fields by name
+    (e.g. dict(track_env=0.0))."""
     gt = eval_mode == 'gt_mpc'
     if gt and value_net is None:
         raise ValueError("eval_mode='gt_mpc' needs value_net")
@@ -81,7 +82,8 @@ def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=
     u_prev = np.tile(np.array([0.0 if gt else 0.1, 0.0]), (E, M, 1))    # evaluate.py:419 (mpc) / 171 (gt_mpc)
     solver = BatchSolver(N=N, dt=dt, n_rk4=n_rk4, C=C, n_obs=M - 1, device=device, dtype=dtype, cand_mode=cand_mode,
                          refine_iters=refine_iters if cand_mode in ('ramp_hold', 'track') else 0,
-                         cost_mode='value_net' if gt else 'progress', **({} if feas_tol is None else {'feas_tol': feas_tol}))
+                         cost_mode='value_net' if gt else 'progress',
+                         **dict({} if feas_tol is None else {'feas_tol': feas_tol}, **(limits or {})))
     if gt:
         solver.set_value_net(**value_net)
         # scenario encodings (mpc.py:336-337, utils.py:84-169): (e_ego, e_other) per problem

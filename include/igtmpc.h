@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IGT_VERSION 200
+#define IGT_VERSION 201
 
 enum {
     IGT_OK = 0,
@@ -55,7 +55,10 @@ enum {
                               base is u_prev held over the horizon or -- igt_solve_batch_ws_* -- the warm start (the
                               previous solution shifted by one step); offsets are dense around 0 (first pass) and, with
                               refine_iters > 0, re-centred on the previous pass's winner with its grid cell's spacing */
-    IGT_CAND_TRACK = 3     /* G x G: acceleration as IGT_CAND_RAMP_HOLD (offset i from the base sequence); STEERING is a
+    IGT_CAND_TRACK = 3     /* G x G: acceleration as IGT_CAND_RAMP_HOLD (offset i from the base sequence) with the target
+                              kept under the envelope E_k = track_env dt^2 (N - k - 1/2) / (2 w_u) -- the acceleration
+                              beyond which one more unit costs more effort (mpc.py:362) than it buys progress
+                              (mpc.py:372); STEERING is a
                               state feedback evaluated inside the roll-out: beta_cmd = clamp(-epsi - track_ke * ey + off_j),
                               df tracks atan(tan(beta_cmd) (l_f + l_r) / l_r) at the steering-rate limit.  Every
                               acceleration profile thereby gets the steering that belongs to where it actually is;
@@ -110,6 +113,7 @@ typedef struct igt_params {
     double track_ke;         /* IGT_CAND_TRACK: lateral-error gain of the steering feedback [1/m]          (0.3)  */
     double track_span;       /* IGT_CAND_TRACK: the G slip-angle offsets span +-track_span [rad]            (0.1)  */
     double track_beta_lim;   /* IGT_CAND_TRACK: |beta_cmd| limit [rad]                                      (0.7)  */
+    double track_env;        /* IGT_CAND_TRACK: scale of the acceleration envelope E_k; 0 = no envelope     (1.0)  */
 } igt_params;
 
 /* Fills *p with the reference's numbers: N=20, dt=0.1, n_rk4=4, C=256, n_obs=1,

@@ -43,10 +43,18 @@ def ambiguous_mask(ref, P, eps_margin=2e-5, eps_cost=2e-5, eps_bp=2e-5, bp=None,
     contender = J <= (best[:, None] + eps_cost)             # could win if verdict flipped
     near_thr = np.abs(g - P.feas_tol) < eps_margin
     amb = (contender & near_thr).any(axis=1)
-    srt = np.sort(Jm, axis=1)
     if ties:
+        # the runner-up that matters is the best candidate whose CONTROLS differ from the winner's: candidates with the
+        # same control sequence (targets clipped to the same envelope / box) are the same arithmetic on the same numbers,
+        # tie exactly on both sides, and the lowest index wins on both sides (test_exact_ties_across_slices_resolve_to_the_lowest_index)
+        rival = Jm
+        if 'U' in ref:
+            Uw = ref['U'][np.arange(J.shape[0]), np.argmin(Jm, axis=1)]
+            rival = np.where((ref['U'] == Uw[:, None]).all(axis=(-1, -2)), np.inf, Jm)
+        else:
+            rival = np.sort(Jm, axis=1)[:, 1:2]
         with np.errstate(invalid='ignore'):
-            amb |= (srt[:, 1] - srt[:, 0]) < eps_cost
+            amb |= (rival.min(axis=1) - best) < eps_cost
     if bp is not None:
         amb |= (contender & (bp < eps_bp)).any(axis=1)
     return amb

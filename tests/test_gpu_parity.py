@@ -617,7 +617,7 @@ def test_tracking_candidates_match_oracle(igt, dtype, tol, eps):
     args = (b['x0'], u_prev, b['kparams'], flags, b['obs_xy'])
     with igt.BatchSolver(dtype=dtype, cand_mode='track') as s0:
         P = oracle_params(s0)
-        assert (s0.params.track_ke, s0.params.track_span, s0.params.track_beta_lim) == (0.3, 0.1, 0.7)
+        assert (s0.params.track_ke, s0.params.track_span, s0.params.track_beta_lim, s0.params.track_env) == (0.3, 0.1, 0.7, 1.0)
         s0.set_cinf(*_cinf())
         all0 = s0.rollout_all(*[a[:48] for a in args], u_ws=u_ws[:48])
         first = s0.solve(*args, u_ws=u_ws)

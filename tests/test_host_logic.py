@@ -141,15 +141,15 @@ def test_c_abi_exports_every_declared_symbol():
     lib = L.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.igt_version() == 200 == int(re.search(r"#define IGT_VERSION (\d+)", hdr).group(1))
+    assert lib.igt_version() == 201 == int(re.search(r"#define IGT_VERSION (\d+)", hdr).group(1))
     p = L.igt_params()
     assert lib.igt_params_default(ct.byref(p)) == 0
     # the numbers MPC_Planner.__init__ hard-codes (mpc.py:45-62)
     assert (p.N, p.n_rk4, p.C, p.n_obs) == (20, 4, 256, 1)
     assert (p.v_min, p.v_max, p.a_min, p.a_max, p.df_max) == (0, 5, -4, 3, 1)
     assert (p.jerk_limit, p.steer_rate_limit, p.ey_lim, p.d_min, p.w_u) == (0.9, 0.7, 0.2, 5.6, 0.05)
-    assert abs(p.l_r - 2.235) < 1e-15 and ct.sizeof(L.igt_params) == 24 + 14 * 8 + 8 + 3 * 8 and p.refine_iters == 0
-    assert (p.track_ke, p.track_span, p.track_beta_lim) == (0.3, 0.1, 0.7)
+    assert abs(p.l_r - 2.235) < 1e-15 and ct.sizeof(L.igt_params) == 24 + 14 * 8 + 8 + 4 * 8 and p.refine_iters == 0
+    assert (p.track_ke, p.track_span, p.track_beta_lim, p.track_env) == (0.3, 0.1, 0.7, 1.0)
     # struct layout agrees with the header's field order
     fields = re.search(r'typedef struct igt_params \{(.*?)\} igt_params;', hdr, re.S).group(1)
     names = re.findall(r'\b(?:int32_t|double)\s+([^;]+);', fields)
