@@ -664,6 +664,47 @@ def test_tracking_candidates_match_oracle(igt, dtype, tol, eps):
     assert first['cost'][both].mean() < rh['cost'][both].mean() - 0.05
 
 
+@pytest.mark.parametrize('env', [0.0, 0.5])
+def test_tracking_envelope_scale_matches_oracle(igt, env):
+    """igt_params.track_env: 0 switches the acceleration envelope off (constant targets), any other scale moves the
+    line E_k = env dt^2 (N - k - 1/2) / (2 w_u); every candidate's controls and the solve agree with the oracle run at
+    the same scale, and the scale changes the answer.  A negative scale is refused."""
+    B = 96
+    b = _batch(B, np.float64)
+    f = lambda k: np.asarray(b[k], dtype=np.float64)
+    args = (b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy'])
+    with igt.BatchSolver(dtype='f64', cand_mode='track', track_env=env) as s:
+        P = oracle_params(s)
+        s.set_cinf(*_cinf())
+        all_ = s.rollout_all(*[a[:32] for a in args])
+        got = s.solve(*args)
+    with igt.BatchSolver(dtype='f64', cand_mode='track') as s1:
+        s1.set_cinf(*_cinf())
+        dflt = s1.solve(*args)
+    ref = O.solve_batch_refined(f('x0'), f('u_prev'), f('kparams'), b['flags'], f('obs_xy'), *_cinf(), P, cand='track',
+                                track=dict(env=env))[0]
+    kp = f('kparams')[:, None, :]
+    x0 = O.apply_flags(f('x0'), b['flags'])[:, None, :]
+    bp = O.breakpoint_distance(x0, ref['U'], kp, P)
+    clear = bp[:32] > 1e-9
+    assert rel_err(all_['U'][clear], ref['U'][:32][clear]).max() <= 1e-12
+    slope = O.track_env_slope(P, env)
+    E = slope * (P.N - np.arange(P.N) - 0.5)
+    a = ref['U'][:, :, 0, :]
+    a_before = np.concatenate([np.broadcast_to(f('u_prev')[:, None, 0, None], a.shape[:2] + (1,)), a[..., :-1]], axis=-1)
+    # above the line a candidate can only be on its way down at the jerk limit
+    assert (a <= np.maximum(E, a_before - P.dt * P.jerk) + 1e-12).all()
+    ok = ~ambiguous_mask(ref, P, 1e-9, 1e-9, 1e-9, bp)
+    assert ok.mean() > 0.7
+    assert (got['argmin'][ok] == ref['argmin'][ok]).all() and (got['status'][ok] == ref['status'][ok]).all()
+    sol = ok & (ref['status'] == 0)
+    assert sol.sum() > 30 and rel_err(got['x'][sol], ref['x'][sol]).max() <= 1e-9
+    both = (got['status'] == 0) & (dflt['status'] == 0)
+    assert np.abs(got['cost'][both] - dflt['cost'][both]).max() > 1e-3
+    with pytest.raises(Exception):
+        igt.BatchSolver(dtype='f64', cand_mode='track', track_env=-1.0)
+
+
 @pytest.mark.parametrize('dtype', ['f64', 'f32'])
 def test_exact_ties_across_slices_resolve_to_the_lowest_index(igt, dtype):
     """Steering-ordered slices hold their columns from the centre outwards, so of EXACTLY tied candidates the lowest

@@ -148,3 +148,34 @@ def test_oracle_closed_loop_and_warm_start_properties():
     xa, ua = CL.augment_prev_sol(np.zeros((7, 11)) + np.array([0, 0, 0, 0, 0, 4.99, 0])[:, None], np.full((2, 10), 0.5),
                                  np.array([np.inf, np.inf, 0.0]), P)
     assert xa.shape == (7, 11) and ua.shape == (2, 10) and xa[5, -1] <= 5.0 and abs(xa[5, -1] - 4.99) < 1e-12   # a = 0 retry
+
+
+def test_tracking_envelope_is_the_stationary_acceleration_of_the_longitudinal_problem():
+    """np_oracle.track_env_slope: E_k = dt^2 (N - k - 1/2) / (2 w_u) is where d/da_k [w_u a_k^2 - progress] = 0 on a
+    straight lane (mpc.py:362, 372) -- checked by finite differences on the oracle's own cost; the tracking candidate
+    with the largest offset follows that line wherever the jerk limit lets it; env = 0 gives the constant targets."""
+    P = O.Params()
+    slope = O.track_env_slope(P)
+    assert slope == P.dt * P.dt / (2 * P.w_u) and O.track_env_slope(P, 0.0) == np.inf
+    E = slope * (P.N - np.arange(P.N) - 0.5)
+    x0 = np.array([0.0, 0.0, 5.0, 0.0, 0.0, 1.0, 0.0])
+    kp = np.array([np.inf, np.inf, 0.0])
+
+    def J(a):
+        U = np.stack([a, np.zeros(P.N)])
+        return float(O.stage_cost(O.rollout_frenet(x0, U, kp, P), U, P))
+
+    for k in (0, 7, 19):
+        g = [(J(E + h * np.eye(P.N)[k]) - J(E - h * np.eye(P.N)[k])) / (2 * h) for h in (1e-4,)][0]
+        assert abs(g) < 1e-8, (k, g)
+    u_prev = np.zeros((1, 2))
+    c, sp = O.track_first_params(u_prev, P)
+    U = O.candidates_track(x0[None], u_prev, kp[None], c, sp, True, P, env_slope=slope)[0]
+    a = U[15 * 16 + 8, 0]                                   # largest acceleration offset, zero steering offset
+    ramp = P.dt * P.jerk * (np.arange(P.N) + 1)
+    k_meet = int(np.argmax(ramp > E))                       # first step at which the ramp would overshoot the line
+    assert np.allclose(a[:k_meet], ramp[:k_meet], atol=1e-15) and k_meet > 5
+    # past the meeting point it comes down at the jerk limit (0.09 per step) towards the line (0.1 per step)
+    assert np.all(np.diff(a[k_meet:]) < 0) and np.all(a[k_meet + 1:] - E[k_meet + 1:] < 0.12) and np.all(a[k_meet:] >= E[k_meet:] - 1e-12)
+    U0 = O.candidates_track(x0[None], u_prev, kp[None], c, sp, True, P)[0]
+    assert np.allclose(U0[15 * 16 + 8, 0], np.minimum(ramp, O.cand_m(15, 16, True) * P.N * P.dt * P.jerk))

@@ -19,7 +19,8 @@ python3 tools/f64_probe.py --flags=0,8 65536 2>&1 | grep -v amdgpu.ids >> $O/${T
 python3 tools/f32_margin_probe.py 2048 2>&1 | grep -v amdgpu.ids > $O/${TAG}_f32_margin.txt
 python3 tools/closed_loop_probe.py f64 > $O/${TAG}_closed_loop.txt 2>&1
 python3 tools/closed_loop_probe.py f64 40 > $O/${TAG}_closed_loop_n40.txt 2>&1
-{ python3 tools/closed_loop_breakdown.py track; python3 tools/closed_loop_breakdown.py ramp_hold; python3 tools/closed_loop_breakdown.py track 40; } 2>&1 | grep -v "^sc " > $O/${TAG}_closed_loop_breakdown.txt
+python3 tools/envelope_sweep.py 2>&1 | grep '^N=' > $O/${TAG}_envelope_sweep.txt
+{ python3 tools/closed_loop_breakdown.py track; python3 tools/closed_loop_breakdown.py ramp_hold; python3 tools/closed_loop_breakdown.py track 40; python3 tools/closed_loop_breakdown.py track 20 1024; python3 tools/closed_loop_breakdown.py track 20 256 2; } 2>&1 | grep -v "^sc \|amdgpu.ids" > $O/${TAG}_closed_loop_breakdown.txt
 echo "[collect] probes done"
 IGT_PMC_DTYPE=f64 IGT_PMC_BATCH=4096 tools/pmc_collect.sh ${TAG}_f64_b4096 > $O/${TAG}_collect_f64_b4096.log 2>&1
 echo "[collect] pmc f64 4096 done"
