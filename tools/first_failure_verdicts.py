@@ -2,7 +2,9 @@
 """Which constraint empties the candidate set when a closed-loop solve fails?  CPU only (oracle/closed_loop.py, the
 float64 restatement of evaluate.py:451-569 with the oracle's shooting solve): 8 scenarios x E episodes x 150 steps,
 tracking candidates + warm start.  For every FIRST failure of an agent (the step before was solved) the verdict bits of
-all 256 candidates are tallied.       python tools/first_failure_verdicts.py [track_env=1.0] [episodes per scenario=4]"""
+all 256 candidates are tallied, and the two profiles that bound what the jerk limit lets the vehicle reach within the
+horizon (acceleration ramping up / down at the limit throughout, each with the 16 steering offsets) are tried on the
+same problem: if they fail too, no acceleration profile avoids the forecast.       python tools/first_failure_verdicts.py [track_env=1.0] [episodes per scenario=4]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'igt-mpc-int_amd')); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -24,12 +26,22 @@ _solve = O.solve_batch_refined
 def recording_solve(*a, **k):
     k['track'] = dict(env=ENV)
     res = _solve(*a, **k)
-    log.append((int(res[-1]['status'][0]), res[-1]['mask'][0].copy()))
+    log.append((int(res[-1]['status'][0]), res[-1]['mask'][0].copy(), a[:5]))
     return res
 
 
+def boundary_profiles_feasible(x0, u_prev, kp, flags, obs):
+    """Full-jerk ramp up and full-jerk ramp down (all 16 acceleration rows collapse to it), 16 steering offsets each."""
+    for sign in (+1.0, -1.0):
+        U = O.candidates_track(O.apply_flags(x0, flags), u_prev, kp, np.array([[sign * 100.0, 0.0]]), np.array([[0.0, 0.1]]), True, P)
+        r = O.solve_batch(x0, u_prev, kp, flags, obs, *cinf, P, U=U, generated=True)
+        if r['status'][0] == 0:
+            return True
+    return False
+
+
 O.solve_batch_refined = recording_solve
-tot = dict(agent_steps=0, infeasible=0, first=0)
+tot = dict(agent_steps=0, infeasible=0, first=0, first_with_a_feasible_boundary_profile=0)
 share = {k: 0.0 for k in BITS}
 every = {k: 0 for k in BITS}
 for sc in range(1, 9):
@@ -47,6 +59,7 @@ for sc in range(1, 9):
                 if st[t, i] != 0 and (t == 0 or st[t - 1, i] == 0):
                     tot['first'] += 1
                     m = log[2 * t + i][1]
+                    tot['first_with_a_feasible_boundary_profile'] += int(boundary_profiles_feasible(*log[2 * t + i][2]))
                     for k, bit in BITS.items():
                         share[k] += float(((m & bit) != 0).mean())
                         every[k] += int(((m & bit) != 0).all())
