@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "igt_math64.h"
+
 namespace igt {
 
 struct KP {  // kernel parameters (by value -> SGPRs)
@@ -56,7 +58,11 @@ struct Ctl {
 // ones).  The realised (a_k, df_k) are an ordinary control sequence: u_out, cost and verdicts are those of the roll-out.
 __device__ __forceinline__ double track_steer(const KP& P, double df_prev, double ey, double ep, double off) {
     const double beta = clampd(-ep - P.trk_ke * ey + off, -P.trk_blim, P.trk_blim);
-    const double cmd = atan(tan(beta) / P.lr_ratio);
+    // cmd = atan(tan(beta) / r) = atan2(sin beta, r cos beta); cos beta > 0 (beta_lim < pi/2, igt_api.hip)
+    double sbt, cbt;
+    if (P.trk_blim < m64::QUADRANT0) m64::sincos_kernel(beta, sbt, cbt);
+    else m64::sincos_reduced(beta, sbt, cbt);
+    const double cmd = m64::atan2_xpos(sbt, P.lr_ratio * cbt);
     return clampd(df_prev + clampd(cmd - df_prev, -P.rate_df, P.rate_df), -P.df_max, P.df_max);
 }
 

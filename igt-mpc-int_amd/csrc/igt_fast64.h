@@ -19,41 +19,17 @@
 // emit (general variant, lanes of different scenarios) and rollout-all agree bit for bit -- asserted in the tests.
 #pragma once
 #include "igt_device.h"
+#include "igt_math64.h"
 
 namespace igt {
 namespace f64 {
 
-// ---- libm-grade sin/cos, used once per control step ------------------------------------------------------------
-// minimax kernels on |r| <= pi/4 (the classical fdlibm coefficient sets), ~1 ulp
-__device__ __forceinline__ void sincos_kernel(double r, double& s, double& c) {
-    const double z = r * r;
-    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = fma(z, ps, 2.75573137070700676789e-06);
-    ps = fma(z, ps, -1.98412698298579493134e-04);
-    ps = fma(z, ps, 8.33333333332248946124e-03);
-    ps = fma(z, ps, -1.66666666666666324348e-01);
-    s = fma(r * z, ps, r);
-    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = fma(z, pc, -2.75573143513906633035e-07);
-    pc = fma(z, pc, 2.48015872894767294178e-05);
-    pc = fma(z, pc, -1.38888888888741095749e-03);
-    pc = fma(z, pc, 4.16666666666666019037e-02);
-    c = fma(z * z, pc, fma(z, -0.5, 1.0));
-}
-// any |x| up to ~1e6: two-term Cody-Waite reduction to |r| <= pi/4
-__device__ __forceinline__ void sincos_reduced(double x, double& s, double& c) {
-    const double kd = __builtin_rint(x * 0.63661977236758134);                   // 2/pi
-    double r = fma(-kd, 1.5707963267948966, x);
-    r = fma(-kd, 6.123233995736766e-17, r);
-    const int q = (int)kd;
-    double sr, cr;
-    sincos_kernel(r, sr, cr);
-    const double a = (q & 1) ? cr : sr;
-    const double b = (q & 1) ? sr : cr;
-    s = (q & 2) ? -a : a;
-    c = ((q + 1) & 2) ? -b : b;
-}
-constexpr double QUADRANT0 = 0.78;     // < pi/4: sincos_reduced() has kd = 0 there, so the kernel alone agrees bit for bit
+using m64::sincos_kernel;
+using m64::sincos_reduced;
+using m64::QUADRANT0;
+using m64::rcp_nr;
+using m64::rsq_nr;
+
 
 // ---- sin/cos of a small stage offset ---------------------------------------------------------------------------
 // |d| <= 0.15: sin to d^9, cos to d^10 (first dropped terms 2e-17 / 2e-19 relative to 1)
@@ -92,23 +68,6 @@ __device__ __forceinline__ void rotate(double& s, double& c, double sd, double c
     const double c_ = fma(c, cd, -(s * sd));
     s = s_; c = c_;
 }
-// 1/x: hardware estimate + two Newton steps (x = 1 gives exactly 1, which the K == 0 identities rely on)
-__device__ __forceinline__ double rcp_nr(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-}
-
-// 1/sqrt(x), x in (0, 1]: hardware estimate + two Newton steps
-__device__ __forceinline__ double rsq_nr(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    const double hx = 0.5 * x;
-    y = y * fma(-(hx * y), y, 1.5);
-    y = y * fma(-(hx * y), y, 1.5);
-    return y;
-}
-
 template <bool HI_ORDER>
 struct Fast64 {
     double h, hh, h6, kv, inv_lr, lr_ratio, b0, b1, dt;

@@ -528,6 +528,14 @@ template <int CAND, bool HI, bool VALUE>
 __global__ __launch_bounds__(64) void search_fast_kernel_o2(IGT_SEARCH_ARGS) {
     search_waves_f32<CAND, HI, VALUE, false>(IGT_SEARCH_PASS);
 }
+// the same kernel held to 256 registers: the tracking family's steering feedback (sincos + atan2 per candidate and step)
+// takes the plain build to 280 and with that to ONE wave per SIMD; a few dwords of scratch buy the second wave back
+// (3.69 vs 5.94 ms at B = 65 536 together with igt_math64.h's atan2).  Not for the other families: the attribute alone
+// costs the lattice kernels 5-7 % (different allocation, same register count).
+template <int CAND, bool HI, bool VALUE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void search_fast_kernel_o2w(IGT_SEARCH_ARGS) {
+    search_waves_f32<CAND, HI, VALUE, false>(IGT_SEARCH_PASS);
+}
 template <int CAND, bool HI, bool VALUE>
 __global__ __launch_bounds__(64) void search_fast_kernel_o2c(IGT_SEARCH_ARGS) {   // leaves horizon checkpoints (carries psi)
     search_waves_f32<CAND, HI, VALUE, true>(IGT_SEARCH_PASS);
@@ -754,6 +762,13 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
 // persistent waves on the per-XCD queues (search_waves), 2 or 3 per SIMD like the float kernels
 template <int CAND, bool HI, bool VALUE>
 __global__ __launch_bounds__(64) void search_f64_kernel_o2(IGT_SEARCH64_ARGS) {
+    search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
+        search_unit64<CAND, HI, VALUE>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN,
+                                       rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg);
+    });
+}
+template <int CAND, bool HI, bool VALUE>      // held to 256 registers for the tracking family (see search_fast_kernel_o2w)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void search_f64_kernel_o2w(IGT_SEARCH64_ARGS) {
     search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
         search_unit64<CAND, HI, VALUE>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN,
                                        rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg);
@@ -1149,6 +1164,10 @@ static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>&
         hipLaunchKernelGGL((search_fast_kernel_o2c<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
                            order, order_stride, A.ckpt, A.ck_parts, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf,
                            A.centre(), A.part_J, A.part_c, A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
+    else if constexpr (CAND == CAND_TRACK)
+        hipLaunchKernelGGL((search_fast_kernel_o2w<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
+                           order, order_stride, A.ckpt, A.ck_parts, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, A.rec_sN,
+                           A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
     else
         hipLaunchKernelGGL((search_fast_kernel_o2<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
                            order, order_stride, A.ckpt, A.ck_parts, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, A.rec_sN,
@@ -1197,6 +1216,10 @@ static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A
     }
     if (o3)
         hipLaunchKernelGGL((search_f64_kernel_o3<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter, order,
+                           order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c,
+                           A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b, A.unit_seg);
+    else if constexpr (CAND == CAND_TRACK)
+        hipLaunchKernelGGL((search_f64_kernel_o2w<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter, order,
                            order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c,
                            A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b, A.unit_seg);
     else

@@ -1,9 +1,23 @@
 #!/bin/bash
-# Runs on the GPU box: the round's evidence in one call -- bench lines, probes and the rocprofv3 passes behind profiles/.
+# Runs on the GPU box: the round's evidence in one call -- the rocprofv3 passes behind profiles/, then bench lines and probes.
 #   usage: tools/r02_collect.sh <tag>        then, back home:  python tools/r02_publish.py <tag>
 TAG=${1:-r02}
 export TMPDIR=/tmp
 O=gpurun_out
+# 1. counter passes first, published into this box's profiles/ so that the bench lines below can quote them
+#    (bench.py only quotes a profile whose source_hash equals the hash of the kernel sources it runs on)
+IGT_PMC_DTYPE=f64 IGT_PMC_BATCH=4096 tools/pmc_collect.sh ${TAG}_f64_b4096 > $O/${TAG}_collect_f64_b4096.log 2>&1
+echo "[collect] pmc f64 4096 done"
+IGT_PMC_DTYPE=f64 IGT_PMC_BATCH=65536 tools/pmc_collect.sh ${TAG}_f64_b65536 --batch 65536 --steps 8 --warmup 2 --no-cpu-baseline --no-secondary --in-flight 1 > $O/${TAG}_collect_f64_b65536.log 2>&1
+echo "[collect] pmc f64 65536 done"
+IGT_PMC_DTYPE=f32 IGT_PMC_BATCH=4096 tools/pmc_collect.sh ${TAG}_f32_b4096 --dtype f32 --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --in-flight 1 > $O/${TAG}_collect_f32_b4096.log 2>&1
+echo "[collect] pmc f32 4096 done"
+IGT_PMC_DTYPE=f32 IGT_PMC_BATCH=65536 tools/pmc_collect.sh ${TAG}_f32_gt1_b65536 --dtype f32 --gt 1 --batch 65536 --steps 8 --warmup 2 --no-secondary --no-cpu-baseline --in-flight 1 > $O/${TAG}_collect_f32_gt1.log 2>&1
+IGT_PMC_DTYPE=f64 IGT_PMC_BATCH=65536 tools/pmc_collect.sh ${TAG}_f64_gt1_b65536 --dtype f64 --gt 1 --batch 65536 --steps 6 --warmup 2 --no-secondary --no-cpu-baseline --in-flight 1 > $O/${TAG}_collect_f64_gt1.log 2>&1
+echo "[collect] pmc gt 65536 done"
+python3 tools/r02_publish.py ${TAG} > $O/${TAG}_publish_on_box.log 2>&1
+echo "[collect] counter summaries published on the box"
+# 2. bench lines, sweeps and probes
 python3 bench.py > $O/${TAG}_bench_b4096.json 2> $O/${TAG}_bench_b4096.err
 echo "[collect] bench 4096 done"
 python3 bench.py --batch 65536 --steps 40 --warmup 5 --no-cpu-baseline --in-flight 1 > $O/${TAG}_bench_b65536.json 2> $O/${TAG}_bench_b65536.err
@@ -16,18 +30,10 @@ done > $O/${TAG}_inflight_sweep.txt
 echo "[collect] in-flight sweep done"
 python3 tools/f64_probe.py 4096 32768 2>&1 | grep -v amdgpu.ids > $O/${TAG}_f64_probe.txt
 python3 tools/f64_probe.py --flags=0,8 65536 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_f64_probe.txt
+python3 tools/family_probe.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_family_probe.txt
 python3 tools/f32_margin_probe.py 2048 2>&1 | grep -v amdgpu.ids > $O/${TAG}_f32_margin.txt
 python3 tools/closed_loop_probe.py f64 > $O/${TAG}_closed_loop.txt 2>&1
 python3 tools/closed_loop_probe.py f64 40 > $O/${TAG}_closed_loop_n40.txt 2>&1
 python3 tools/envelope_sweep.py 2>&1 | grep '^N=' > $O/${TAG}_envelope_sweep.txt
 { python3 tools/closed_loop_breakdown.py track; python3 tools/closed_loop_breakdown.py ramp_hold; python3 tools/closed_loop_breakdown.py track 40; python3 tools/closed_loop_breakdown.py track 20 1024; python3 tools/closed_loop_breakdown.py track 20 256 2; } 2>&1 | grep -v "^sc \|amdgpu.ids" > $O/${TAG}_closed_loop_breakdown.txt
 echo "[collect] probes done"
-IGT_PMC_DTYPE=f64 IGT_PMC_BATCH=4096 tools/pmc_collect.sh ${TAG}_f64_b4096 > $O/${TAG}_collect_f64_b4096.log 2>&1
-echo "[collect] pmc f64 4096 done"
-IGT_PMC_DTYPE=f64 IGT_PMC_BATCH=65536 tools/pmc_collect.sh ${TAG}_f64_b65536 --batch 65536 --steps 8 --warmup 2 --no-cpu-baseline --no-secondary --in-flight 1 > $O/${TAG}_collect_f64_b65536.log 2>&1
-echo "[collect] pmc f64 65536 done"
-IGT_PMC_DTYPE=f32 IGT_PMC_BATCH=4096 tools/pmc_collect.sh ${TAG}_f32_b4096 --dtype f32 --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --in-flight 1 > $O/${TAG}_collect_f32_b4096.log 2>&1
-echo "[collect] pmc f32 4096 done"
-IGT_PMC_DTYPE=f32 IGT_PMC_BATCH=65536 tools/pmc_collect.sh ${TAG}_f32_gt1_b65536 --dtype f32 --gt 1 --batch 65536 --steps 8 --warmup 2 --no-secondary --no-cpu-baseline --in-flight 1 > $O/${TAG}_collect_f32_gt1.log 2>&1
-IGT_PMC_DTYPE=f64 IGT_PMC_BATCH=65536 tools/pmc_collect.sh ${TAG}_f64_gt1_b65536 --dtype f64 --gt 1 --batch 65536 --steps 6 --warmup 2 --no-secondary --no-cpu-baseline --in-flight 1 > $O/${TAG}_collect_f64_gt1.log 2>&1
-echo "[collect] pmc gt 65536 done"
