@@ -47,7 +47,7 @@ def initial_states(rng, route_pairs):
     return x, rid
 
 
-def run_closed_loop(sc=1, num_samples=1, N=20, dt=0.1, T_sim=15.0, seed=2026, C=256, n_rk4=4, device=0,
+def run_closed_loop(sc=1, num_samples=1, N=40, dt=0.1, T_sim=15.0, seed=2026, C=256, n_rk4=4, device=0,
                     dtype='f64', rotation=None, cand_mode='track', refine_iters=0, verbose=False,
                     eval_mode='mpc', value_net=None, device_resident=False, warm_start=True, init=None,
                     terminal_set=True, feas_tol=None, limits=None):
@@ -248,7 +248,7 @@ def main():
     ap = argparse.ArgumentParser(description='batched closed-loop evaluation (counterpart of evaluate.py --eval_mode mpc)')
     ap.add_argument('--sc', type=int, default=1)
     ap.add_argument('--num_samples', type=int, default=1)
-    ap.add_argument('--N', type=int, default=20)
+    ap.add_argument('--N', type=int, default=40, help='horizon; mpc.yaml:6 ships 40 (BASELINE.json benchmarks 20)')
     ap.add_argument('--C', type=int, default=256)
     ap.add_argument('--eval_mode', default='mpc', choices=['mpc', 'gt_mpc'])
     ap.add_argument('--value_net', default=None, help='gt_mpc: .npz with W0,b0,W1,b1,... (optionally prefixed, see --net_prefix)')

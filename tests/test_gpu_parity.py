@@ -664,6 +664,30 @@ def test_tracking_candidates_match_oracle(igt, dtype, tol, eps):
     assert first['cost'][both].mean() < rh['cost'][both].mean() - 0.05
 
 
+def test_tracking_steering_feedback_over_its_whole_range(igt):
+    """The steering command atan(tan(beta)/r) is evaluated on the device as atan2(sin beta, r cos beta) with an interval
+    reduction of its own (igt_math64.h): with |beta| allowed up to 1.4 rad, offsets of +-1.2 rad and a lateral gain of 2
+    every interval of the reduction (|t| up to 11.6) and the range-reduced sincos are exercised; every candidate's
+    controls must still be the numpy oracle's np.arctan(np.tan(beta)/r) chain to 1e-12."""
+    B = 64
+    b = _batch(B, np.float64)
+    f = lambda k: np.asarray(b[k], dtype=np.float64)
+    args = (b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy'])
+    tk = dict(ke=2.0, span=1.2, blim=1.4)
+    with igt.BatchSolver(dtype='f64', cand_mode='track', track_ke=tk['ke'], track_span=tk['span'], track_beta_lim=tk['blim']) as s:
+        P = oracle_params(s)
+        s.set_cinf(*_cinf())
+        all_ = s.rollout_all(*args)
+    ref = O.solve_batch_refined(f('x0'), f('u_prev'), f('kparams'), b['flags'], f('obs_xy'), *_cinf(), P, cand='track', track=tk)[0]
+    x0 = O.apply_flags(f('x0'), b['flags'])[:, None, :]
+    clear = O.breakpoint_distance(x0, ref['U'], f('kparams')[:, None, :], P) > 1e-9
+    d = ref['U'][:, :, 1, :]
+    assert np.abs(d).max() > 0.99 and (np.abs(np.diff(d, axis=-1)).max() > 0.069)      # box and rate limits are reached
+    assert rel_err(all_['U'][clear], ref['U'][clear]).max() <= 1e-12
+    fin = clear & np.isfinite(ref['X']).all(axis=(-1, -2))
+    assert rel_err(all_['X'][fin], ref['X'][fin]).max() <= 1e-9
+
+
 @pytest.mark.parametrize('env', [0.0, 0.5])
 def test_tracking_envelope_scale_matches_oracle(igt, env):
     """igt_params.track_env: 0 switches the acceleration envelope off (constant targets), any other scale moves the
