@@ -251,7 +251,7 @@ def main():
             layers.append((g[f'sc{args.gt}_W{i}'], g[f'sc{args.gt}_b{i}']))
             i += 1
 
-    def measure(dtype, Bm, steps, warmup, in_flight=None):
+    def measure(dtype, Bm, steps, warmup, in_flight=None, cand_mode='lattice'):
         """W untimed + K timed steps of the `dtype` entry point at Bm scenarios per GPU, then per-kernel HIP events."""
         npdt = np.float64 if dtype == 'f64' else np.float32
         td = torch.float64 if dtype == 'f64' else torch.float32
@@ -261,7 +261,8 @@ def main():
         F = in_flight or args.in_flight
         solvers, outs, lanes = [], [], []
         for _ in range(F):
-            sv = BatchSolver(N=N, C=C, n_obs=1, device=dev, dtype=dtype, cost_mode='value_net' if args.gt else 'progress')
+            sv = BatchSolver(N=N, C=C, n_obs=1, device=dev, dtype=dtype, cost_mode='value_net' if args.gt else 'progress',
+                             cand_mode=cand_mode)
             sv.set_cinf(*cinf_halfplanes(dt=sv.params.dt, jerk=sv.params.jerk_limit))
             if args.gt:
                 sv.set_value_net(layers)      # identity whitening: the reference's statistics are not shipped
@@ -351,6 +352,9 @@ def main():
         same_work = measure(args.dtype, default_batch(1), args.steps, args.warmup)
     # one solve at a time (every step waits for the previous one's emit pass), for comparison with the pipelined headline
     serial = measure(args.dtype, B, args.steps, args.warmup, in_flight=1) if args.in_flight > 1 and not args.no_secondary else None
+    # the candidate family the planner and the closed-loop driver use by default (state-feedback steering):
+    # the headline stays on SURVEY 8d's lattice, this is the same batch through the family that gives the better answers
+    tracking = None if args.no_secondary else measure(args.dtype, B, args.steps, args.warmup, cand_mode='track')
 
     if rank == 0:
         search_ms, emit_ms, rd = head['search_ms'], head['emit_ms'], head['rd']
@@ -416,6 +420,13 @@ def main():
                           'f32': 'igt_solve_batch_f32: <= 1e-5*max(1,|ref|) except trajectories whose curvature switch is '
                                  'decided inside float32 noise (share measured in tests/test_gpu_parity.py)'},
         }
+        if tracking is not None:
+            line['tracking_family'] = {
+                'value': tracking['value'], 'unit': 'solves/s', 'ms_per_step': tracking['ms_per_step'], 'dtype': args.dtype,
+                'kernels_ms': {'search': tracking['search_ms'], 'emit': tracking['emit_ms']},
+                'feasible_fraction': tracking['feasible'],
+                'note': 'same batch, entry point and timing with cand_mode = IGT_CAND_TRACK (256 candidates, one pass): '
+                        'the default family of MPC_Planner and igtmpc.evaluate'}
         if other is not None:
             line[f'{other_dtype}_path'] = {
                 'value': other['value'], 'unit': 'solves/s', 'ms_per_step': other['ms_per_step'], 'dtype': other_dtype,
