@@ -50,7 +50,7 @@ def initial_states(rng, route_pairs):
 def run_closed_loop(sc=1, num_samples=1, N=40, dt=0.1, T_sim=15.0, seed=2026, C=256, n_rk4=4, device=0,
                     dtype='f64', rotation=None, cand_mode='track', refine_iters=0, verbose=False,
                     eval_mode='mpc', value_net=None, device_resident=False, warm_start=True, init=None,
-                    terminal_set=True, feas_tol=None, limits=None):
+                    terminal_set=True, feas_tol=None, limits=None, graph=False):
     """eval_mode 'mpc' (evaluate.py:370-639) or 'gt_mpc' (123-369: terminal value network in the cost; needs
     value_net = dict(layers=[(W,b),...][, Wn, mu_f, sigma_t, mu_t]) -- the reference's normalisation statistics are
     not shipped, identity by default).  device_resident=True keeps every per-step array in HBM (torch tensors;
@@ -60,7 +60,7 @@ def run_closed_loop(sc=1, num_samples=1, N=40, dt=0.1, T_sim=15.0, seed=2026, C=
     init = (x[E,M,7], route_pairs[E]) overrides the sampled initial states; terminal_set=False drops the C_inf
     constraint (mpc.py:177-180) -- a test switch.  feas_tol: inequality tolerance of the verdicts (default: the
     library's 1e-6; IPOPT's constr_viol_tol is 1e-3, mpc.py:135); limits: further igt_params fields by name
-    (e.g. dict(track_env=0.0))."""
+    (e.g. dict(track_env=0.0)).  graph=True (with device_resident): the time loop replays one captured step."""
     gt = eval_mode == 'gt_mpc'
     if gt and value_net is None:
         raise ValueError("eval_mode='gt_mpc' needs value_net")
@@ -99,7 +99,8 @@ def run_closed_loop(sc=1, num_samples=1, N=40, dt=0.1, T_sim=15.0, seed=2026, C=
     npdt = solver.np_dtype
 
     if device_resident:
-        out = _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc if gt else None, gt, E, M, N, M_sim, device, warm)
+        out = _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc if gt else None, gt, E, M, N, M_sim, device, warm,
+                           graph=graph)
         solver.close()
         stepper.close()
         out['routes'] = pairs
@@ -177,13 +178,17 @@ def shift_controls(u):
     return torch.cat([u[..., 1:], u[..., -1:]], dim=-1)
 
 
-def _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc, gt, E, M, N, M_sim, device, warm):
-    """The same time loop with every array resident in HBM (float64 state, solver-dtype views per call)."""
+def _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc, gt, E, M, N, M_sim, device, warm, graph=False):
+    """The same time loop with every array resident in HBM (float64 state, solver-dtype views per call).
+    graph=True: steps 0 and 1 run eagerly, then ONE step -- forecast, solve, fallback step and the ~40 small tensor
+    operations between them -- is captured in a stream graph and replayed for the remaining steps (the state lives in
+    fixed buffers that the captured step updates in place; the column of x_data / u_data it writes is a device-side
+    counter).  The loop is launch-bound at a few hundred problems per step; the replay removes the launches."""
     import torch
     dev = torch.device('cuda', device)
     td = torch.float32 if solver.dtype == 'f32' else torch.float64
     T = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
-    x, u_prev, kp = T(x), T(u_prev), T(kp)
+    x, u_prev, kp = T(x).clone(), T(u_prev).clone(), T(kp)
     kp_s = kp.reshape(E * M, 3).to(td).contiguous()
     kp_d = kp.reshape(E * M, 3).contiguous()
     flags_t = torch.as_tensor(flags.astype(np.int32), device=dev)
@@ -198,21 +203,20 @@ def _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc, gt, E, M, N, M
     sol_u = torch.zeros((E, M, 2, N), dtype=td, device=dev)
     ix = torch.tensor([0, 1, 6], device=dev)
     io = torch.tensor([0, 1, 2, 5], device=dev)
-    torch.cuda.synchronize(dev)
-    t_start = time.perf_counter()
-    for t in range(M_sim):
+    col = torch.zeros(1, dtype=torch.int64, device=dev)            # the step the next call of step() computes
+    a_fc0 = torch.as_tensor(0.09 * (np.arange(M)[::-1] + 1.0), device=dev).expand(E, M) if gt else None
+
+    def step(first):
         xo, uo = x.flip(1), u_prev.flip(1)
-        a_fc = uo[..., 0]
-        if gt and t == 0:
-            a_fc = torch.as_tensor(0.09 * (np.arange(M)[::-1] + 1.0), device=dev).expand(E, M)
-        hp = (have_sol.flip(1) & (t > 0)).reshape(-1).to(torch.int32).contiguous()
+        a_fc = a_fc0 if (gt and first) else uo[..., 0]
+        hp = (have_sol.flip(1) & (not first)).reshape(-1).to(torch.int32).contiguous()
         obs, tv = solver.forecast(x.index_select(2, ix).reshape(E * M, 3).to(td).contiguous(),
                                   xo.index_select(2, io).reshape(E * M, 4).to(td).contiguous(),
                                   a_fc.reshape(-1).to(td).contiguous(), rid_o,
                                   sol_x.flip(1).reshape(E * M, 7, N + 1).contiguous(),
                                   sol_u.flip(1).reshape(E * M, 2, N).contiguous(), hp)
         fl, u_ws = flags_t, None
-        if warm and t > 0:
+        if warm and not first:
             fl = flags_t | (have_sol.reshape(-1).to(torch.int32) * IGT_FLAG_WARM)
             u_ws = shift_controls(sol_u).reshape(E * M, 2, N).contiguous()
         out = solver.solve(x.reshape(E * M, 7).to(td).contiguous(), u_prev.reshape(E * M, 2).to(td).contiguous(), kp_s,
@@ -230,12 +234,37 @@ def _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc, gt, E, M, N, M
         stop = x.clone()
         stop[..., 5] = 0.0
         nxt_fb = torch.where(neg[..., None], stop, nxt_fb)
-        x = torch.where(ok[..., None], xs[:, :, :, 1].to(torch.float64), nxt_fb)
-        u_prev = torch.where(ok[..., None], us[:, :, :, 0].to(torch.float64), u_fb)
-        infeasible += (~ok).to(torch.int64)
-        have_sol, sol_x, sol_u = ok, torch.nan_to_num(xs), torch.nan_to_num(us)
-        x_data[:, :, t + 1] = x.reshape(E, 7 * M)
-        u_data[:, :, t] = u_prev.reshape(E, 2 * M)
+        x_new = torch.where(ok[..., None], xs[:, :, :, 1].to(torch.float64), nxt_fb)
+        u_new = torch.where(ok[..., None], us[:, :, :, 0].to(torch.float64), u_fb)
+        x.copy_(x_new)
+        u_prev.copy_(u_new)
+        infeasible.add_((~ok).to(torch.int64))
+        have_sol.copy_(ok)
+        sol_x.copy_(torch.nan_to_num(xs))
+        sol_u.copy_(torch.nan_to_num(us))
+        u_data.index_copy_(2, col, u_prev.reshape(E, 2 * M, 1))
+        col.add_(1)
+        x_data.index_copy_(2, col, x.reshape(E, 7 * M, 1))
+
+    torch.cuda.synchronize(dev)
+    t_start = time.perf_counter()
+    step(True)
+    t = 1
+    if graph and M_sim > 3:
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            step(False)                        # warm-up of the generic step on the capture stream (workspaces are sized now)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        t = 2
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            step(False)
+        for _ in range(t, M_sim):
+            g.replay()
+        t = M_sim
+    for _ in range(t, M_sim):
+        step(False)
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t_start
     xd = x_data.cpu().numpy()
@@ -255,6 +284,7 @@ def main():
     ap.add_argument('--net_prefix', default='', help="key prefix inside the npz, e.g. 'sc1_'")
     ap.add_argument('--verbose', action='store_true')
     ap.add_argument('--device_resident', action='store_true', help='keep all per-step arrays in HBM (torch tensors)')
+    ap.add_argument('--graph', action='store_true', help='with --device_resident: capture one step in a stream graph and replay it')
     ap.add_argument('--cand_mode', default='track', choices=['lattice', 'ramp_hold', 'track'])
     ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
     a = ap.parse_args()
@@ -269,7 +299,7 @@ def main():
             i += 1
         net = dict(layers=layers)
     r = run_closed_loop(sc=a.sc, num_samples=a.num_samples, N=a.N, C=a.C, verbose=a.verbose, eval_mode=a.eval_mode,
-                        value_net=net, device_resident=a.device_resident, cand_mode=a.cand_mode, dtype=a.dtype)
+                        value_net=net, device_resident=a.device_resident, cand_mode=a.cand_mode, dtype=a.dtype, graph=a.graph)
     print(json.dumps({'sc': a.sc, 'episodes': a.num_samples, 'routes': r['routes'][:4],
                       'infeasible_ratio_mean': r['infeasible_ratio'].mean(axis=0).tolist(),
                       'deadlock_rate': float(r['deadlock'].mean()),

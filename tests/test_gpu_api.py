@@ -216,6 +216,26 @@ def test_closed_loop_device_resident_equals_host_loop():
         assert np.array_equal(a['infeasible_ratio'], b['infeasible_ratio'])
 
 
+def test_closed_loop_replayed_from_a_stream_graph_equals_the_eager_loop(golden_dir):
+    """device_resident + graph: after two eager steps ONE step (forecast, solve, fallback step and the tensor operations
+    between them) is captured and replayed for the rest of the episode; trajectories, applied inputs and infeasible
+    counts are those of the eager device loop bit for bit -- tracking candidates + warm start, the lattice, and the
+    gt_mpc loop (value network inside the captured solve)."""
+    from igtmpc.evaluate import run_closed_loop
+    v = np.load(f'{golden_dir}/value_net_golden.npz')
+    layers, i = [], 0
+    while f'sc1_W{i}' in v:
+        layers.append((v[f'sc1_W{i}'], v[f'sc1_b{i}']))
+        i += 1
+    for kw in (dict(sc=2, cand_mode='track'), dict(sc=7, cand_mode='lattice'),
+               dict(sc=1, cand_mode='track', eval_mode='gt_mpc', value_net=dict(layers=layers))):
+        a = run_closed_loop(num_samples=8, N=20, T_sim=3.0, device_resident=True, **kw)
+        b = run_closed_loop(num_samples=8, N=20, T_sim=3.0, device_resident=True, graph=True, **kw)
+        assert np.array_equal(a['x_data'], b['x_data']) and np.array_equal(a['u_data'], b['u_data']), kw
+        assert np.array_equal(a['infeasible_ratio'], b['infeasible_ratio']) and np.array_equal(a['deadlock'], b['deadlock'])
+        assert np.abs(b['u_data'][:, :, -1]).max() > 0          # the last column was written by the last replay
+
+
 def test_mpc_planner_gt_mode(golden_dir):
     """use_NN_cost2go=True (evaluate.py:191): the planner drives the value-net cost through the same call
     sequence and agrees with the oracle."""

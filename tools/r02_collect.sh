@@ -34,6 +34,7 @@ python3 tools/family_probe.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_family_probe
 python3 tools/f32_margin_probe.py 2048 2>&1 | grep -v amdgpu.ids > $O/${TAG}_f32_margin.txt
 python3 tools/closed_loop_probe.py f64 > $O/${TAG}_closed_loop.txt 2>&1
 python3 tools/closed_loop_probe.py f64 40 > $O/${TAG}_closed_loop_n40.txt 2>&1
+python3 tools/closed_loop_scale.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_closed_loop_scale.txt
 python3 tools/envelope_sweep.py 2>&1 | grep '^N=' > $O/${TAG}_envelope_sweep.txt
 { python3 tools/closed_loop_breakdown.py track; python3 tools/closed_loop_breakdown.py ramp_hold; python3 tools/closed_loop_breakdown.py track 40; python3 tools/closed_loop_breakdown.py track 20 1024; python3 tools/closed_loop_breakdown.py track 20 256 2; } 2>&1 | grep -v "^sc \|amdgpu.ids" > $O/${TAG}_closed_loop_breakdown.txt
 echo "[collect] probes done"
