@@ -9,6 +9,7 @@ from .vehicle import Curvature, VehicleAction, VehicleReference, VehicleState  #
 from .predictor import ConstantAccelerationModel, PredictorBase  # noqa: F401
 from .models import KinematicBicycleModel, KinematicBicycleModelFrenet  # noqa: F401
 from .planner import MPC_Planner  # noqa: F401
+from .value_nets import shipped_value_net  # noqa: F401
 
 __all__ = ['BatchSolver', 'IgtError', 'load_library', 'MPC_Planner', 'VehicleState', 'VehicleAction',
            'VehicleReference', 'Curvature', 'PredictorBase', 'ConstantAccelerationModel',

@@ -24,6 +24,7 @@ from . import routes as R
 from .cinf import cinf_halfplanes
 from ._lib import IGT_FLAG_WARM
 from .solver import BatchSolver
+from .value_nets import shipped_value_net
 
 A_MIN_POLICY = -4.0        # mpc.yaml:8, used by the brake fallback (evaluate.py:514)
 
@@ -51,9 +52,9 @@ def run_closed_loop(sc=1, num_samples=1, N=40, dt=0.1, T_sim=15.0, seed=2026, C=
                     dtype='f64', rotation=None, cand_mode='track', refine_iters=0, verbose=False,
                     eval_mode='mpc', value_net=None, device_resident=False, warm_start=True, init=None,
                     terminal_set=True, feas_tol=None, limits=None, graph=False):
-    """eval_mode 'mpc' (evaluate.py:370-639) or 'gt_mpc' (123-369: terminal value network in the cost; needs
-    value_net = dict(layers=[(W,b),...][, Wn, mu_f, sigma_t, mu_t]) -- the reference's normalisation statistics are
-    not shipped, identity by default).  device_resident=True keeps every per-step array in HBM (torch tensors;
+    """eval_mode 'mpc' (evaluate.py:370-639) or 'gt_mpc' (123-369: terminal value network in the cost;
+    value_net = dict(layers=[(W,b),...][, Wn, mu_f, sigma_t, mu_t]), default: the network the reference ships for
+    scenario sc -- its normalisation statistics are not shipped, identity unless given).  device_resident=True keeps every per-step array in HBM (torch tensors;
     forecast, solve, fallback step and the state update never leave the GPU) -- for thousands of episodes.
     warm_start (ramp-hold candidates): an agent that solved the previous step centres its candidates on that solution
     shifted by one step (evaluate.py:478-481, utils.py:354-363 augment_prev_sol) instead of on u_prev held.
@@ -63,7 +64,9 @@ def run_closed_loop(sc=1, num_samples=1, N=40, dt=0.1, T_sim=15.0, seed=2026, C=
     (e.g. dict(track_env=0.0)).  graph=True (with device_resident): the time loop replays one captured step."""
     gt = eval_mode == 'gt_mpc'
     if gt and value_net is None:
-        raise ValueError("eval_mode='gt_mpc' needs value_net")
+        if init is not None:
+            raise ValueError("eval_mode='gt_mpc' with init= needs value_net (the shipped networks are per scenario)")
+        value_net = shipped_value_net(sc)                               # sc{n}_config.yaml:2 model_path
     rng = np.random.default_rng(seed)                                   # evaluate.py:35, 56
     M = 2
     M_sim = int(round(T_sim / dt))                                      # evaluate.py:83-84
@@ -280,7 +283,8 @@ def main():
     ap.add_argument('--N', type=int, default=40, help='horizon; mpc.yaml:6 ships 40 (BASELINE.json benchmarks 20)')
     ap.add_argument('--C', type=int, default=256)
     ap.add_argument('--eval_mode', default='mpc', choices=['mpc', 'gt_mpc'])
-    ap.add_argument('--value_net', default=None, help='gt_mpc: .npz with W0,b0,W1,b1,... (optionally prefixed, see --net_prefix)')
+    ap.add_argument('--value_net', default=None, help='gt_mpc: .npz with W0,b0,W1,b1,... (optionally prefixed, see --net_prefix); '
+                    'default: the network shipped for --sc')
     ap.add_argument('--net_prefix', default='', help="key prefix inside the npz, e.g. 'sc1_'")
     ap.add_argument('--verbose', action='store_true')
     ap.add_argument('--device_resident', action='store_true', help='keep all per-step arrays in HBM (torch tensors)')
@@ -290,14 +294,13 @@ def main():
     a = ap.parse_args()
     net = None
     if a.eval_mode == 'gt_mpc':
-        if not a.value_net:
-            ap.error('--eval_mode gt_mpc needs --value_net')
-        z = np.load(a.value_net)
-        layers, i = [], 0
-        while f'{a.net_prefix}W{i}' in z:
-            layers.append((z[f'{a.net_prefix}W{i}'], z[f'{a.net_prefix}b{i}']))
-            i += 1
-        net = dict(layers=layers)
+        if a.value_net:
+            z = np.load(a.value_net)
+            layers, i = [], 0
+            while f'{a.net_prefix}W{i}' in z:
+                layers.append((z[f'{a.net_prefix}W{i}'], z[f'{a.net_prefix}b{i}']))
+                i += 1
+            net = dict(layers=layers)
     r = run_closed_loop(sc=a.sc, num_samples=a.num_samples, N=a.N, C=a.C, verbose=a.verbose, eval_mode=a.eval_mode,
                         value_net=net, device_resident=a.device_resident, cand_mode=a.cand_mode, dtype=a.dtype, graph=a.graph)
     print(json.dumps({'sc': a.sc, 'episodes': a.num_samples, 'routes': r['routes'][:4],

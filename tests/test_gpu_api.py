@@ -201,8 +201,11 @@ def test_closed_loop_gt_mpc_mode(golden_dir):
     assert r['x_data'].shape == (4, 14, 21) and np.isfinite(r['x_data']).all()
     m = run_closed_loop(sc=1, num_samples=4, N=20, T_sim=2.0)
     assert not np.array_equal(r['u_data'], m['u_data'])          # the terminal value changes the decisions
-    with pytest.raises(ValueError):
-        run_closed_loop(sc=1, num_samples=1, eval_mode='gt_mpc')
+    # without value_net the driver takes the network the reference ships for the scenario (sc1_config.yaml:2)
+    d = run_closed_loop(sc=1, num_samples=4, N=20, T_sim=2.0, eval_mode='gt_mpc')
+    assert np.array_equal(d['x_data'], r['x_data']) and np.array_equal(d['u_data'], r['u_data'])
+    r6 = run_closed_loop(sc=6, num_samples=2, N=20, T_sim=1.0, eval_mode='gt_mpc')        # a 3-hidden-layer one
+    assert np.isfinite(r6['x_data']).all()
 
 
 def test_closed_loop_device_resident_equals_host_loop():

@@ -179,3 +179,25 @@ def test_tracking_envelope_is_the_stationary_acceleration_of_the_longitudinal_pr
     assert np.all(np.diff(a[k_meet:]) < 0) and np.all(a[k_meet + 1:] - E[k_meet + 1:] < 0.12) and np.all(a[k_meet:] >= E[k_meet:] - 1e-12)
     U0 = O.candidates_track(x0[None], u_prev, kp[None], c, sp, True, P)[0]
     assert np.allclose(U0[15 * 16 + 8, 0], np.minimum(ramp, O.cand_m(15, 16, True) * P.N * P.dt * P.jerk))
+
+
+def test_all_eight_shipped_value_networks_reproduce_the_reference_forward(golden_dir):
+    """igtmpc/data/value_nets.npz (weights of V_GT_sc1..8, exported as data) through the oracle's forward pass gives the
+    outputs the reference's own model.py produced on the golden inputs (tests/golden/make_golden.py, V_sc{n}); the two
+    networks that also travel inside the golden file are the same arrays."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'igt-mpc-int_amd'))
+    from igtmpc.value_nets import shipped_value_net
+    g = np.load(f'{golden_dir}/value_net_golden.npz')
+    hidden = {}
+    for sc in range(1, 9):
+        net = shipped_value_net(sc)
+        hidden[sc] = len(net['layers']) - 1
+        got = O.value_net_forward(net['layers'], g['z'])
+        assert np.abs(got.reshape(-1) - g[f'V_sc{sc}']).max() <= 1e-12, sc
+    assert hidden == {1: 2, 2: 2, 3: 3, 4: 2, 5: 2, 6: 3, 7: 3, 8: 2}
+    for sc in (1, 3):
+        for i, (W, b) in enumerate(shipped_value_net(sc)['layers']):
+            assert np.array_equal(W, g[f'sc{sc}_W{i}']) and np.array_equal(b, g[f'sc{sc}_b{i}'])
+    with pytest.raises(ValueError):
+        shipped_value_net(9)
