@@ -31,6 +31,7 @@ echo "[collect] in-flight sweep done"
 python3 tools/f64_probe.py 4096 32768 2>&1 | grep -v amdgpu.ids > $O/${TAG}_f64_probe.txt
 python3 tools/f64_probe.py --flags=0,8 65536 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_f64_probe.txt
 python3 tools/family_probe.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_family_probe.txt
+python3 tools/latency_probe.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_latency.txt
 python3 tools/f32_margin_probe.py 2048 2>&1 | grep -v amdgpu.ids > $O/${TAG}_f32_margin.txt
 python3 tools/closed_loop_probe.py f64 > $O/${TAG}_closed_loop.txt 2>&1
 python3 tools/closed_loop_probe.py f64 40 > $O/${TAG}_closed_loop_n40.txt 2>&1

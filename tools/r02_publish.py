@@ -12,7 +12,7 @@ def cp(src, dst):
         print('MISSING', src)
 for k in ('bench_b4096', 'bench_b65536', 'bench_gt_sc1_b65536', 'bench_gt_sc3_b65536'):
     cp(f'{tag}_{k}.json', f'r02_{k}.json')
-for k in ('inflight_sweep', 'f64_probe', 'family_probe', 'f32_margin', 'closed_loop', 'closed_loop_n40', 'closed_loop_breakdown', 'closed_loop_scale', 'envelope_sweep'):
+for k in ('inflight_sweep', 'f64_probe', 'family_probe', 'latency', 'f32_margin', 'closed_loop', 'closed_loop_n40', 'closed_loop_breakdown', 'closed_loop_scale', 'envelope_sweep'):
     cp(f'{tag}_{k}.txt', f'r02_{k}.txt')
 for k in ('f64_b4096', 'f64_b65536', 'f32_b4096', 'f32_gt1_b65536', 'f64_gt1_b65536'):
     cp(f'{tag}_{k}/summary.json', f'r02_pmc_{k}.json')
