@@ -43,6 +43,7 @@ struct igt_handle {
     bool net_set;
     void* d_stage;
     size_t stage_bytes;
+    void* h_stage;         // pinned mirror of the first PACK_BYTES of d_stage (small host-mode solves: one copy each way)
     void* d_work;          // workspace: per-slice partial arg-min, value-net records
     size_t work_bytes;
     double* d_routes;      // [n_routes, 12] route geometry for the forecast kernel
@@ -157,7 +158,14 @@ igt::KP make_kp(const igt_params& p, int F) {
     return k;
 }
 
+// A host-mode solve of a few scenarios is a dozen sub-kilobyte copies around ~120 us of kernels, and every pageable
+// hipMemcpyAsync costs ~7 us whatever its size.  Up to PACK_BYTES the inputs are gathered into a pinned mirror of the
+// staging arena and cross the bus in ONE copy, the outputs come back in one; beyond that the copies go directly (a second
+// pass over megabytes on the host would cost more than the calls).
+constexpr size_t PACK_BYTES = 256 * 1024;
+
 int ensure_stage(igt_handle* h, size_t bytes) {
+    if (!h->h_stage) HIPCHK(hipHostMalloc(&h->h_stage, PACK_BYTES, hipHostMallocDefault));
     if (bytes <= h->stage_bytes) return 0;
     if (h->d_stage) { HIPCHK(hipFree(h->d_stage)); h->d_stage = nullptr; h->stage_bytes = 0; }
     const size_t want = bytes + bytes / 4 + 4096;
@@ -230,6 +238,8 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     const size_t n_xo = (size_t)B * 7 * (p.N + 1), n_uo = (size_t)B * 2 * p.N;
 
     igt::SolveArgs<T> A{};
+    bool packed = false;                 // host mode, small: one copy each way through the pinned mirror (ensure_stage)
+    size_t out_begin = 0, out_end = 0;
     A.table = h->table_set ? h->d_table : nullptr;
     A.cinf = h->kp.F > 0 ? h->d_cinf : nullptr;
     if (mem == IGT_MEM_DEVICE) {
@@ -240,26 +250,43 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
         const size_t bytes = (n_x + 3 * n_u + n_k + n_obs + n_xo + 2 * n_uo + B) * sizeof(T) + (size_t)B * 12 + 24 * 256;
         if (int rc = ensure_stage(h, bytes)) return rc;
         Arena ar{(char*)h->d_stage, 0};
+        // inputs first, outputs behind them: each group is one contiguous span of the arena
         T* dx0 = ar.take<T>(n_x); T* dup = ar.take<T>(n_u); T* dk = ar.take<T>(n_k);
         uint32_t* dfl = ar.take<uint32_t>(B); T* dob = ar.take<T>(n_obs ? n_obs : 1);
-        T* dxo = ar.take<T>(n_xo); T* duo = ar.take<T>(n_uo); T* dco = ar.take<T>(B);
-        int32_t* dam = ar.take<int32_t>(B); int32_t* dst = ar.take<int32_t>(B);
         T* dtv = ar.take<T>(n_u); T* den = ar.take<T>(n_u);
-        if (value) {
-            HIPCHK(hipMemcpyAsync(dtv, tv_sv, n_u * sizeof(T), hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(den, enc, n_u * sizeof(T), hipMemcpyHostToDevice, st));
+        T* dws = u_ws ? ar.take<T>(n_uo) : nullptr;
+        const size_t in_span = ar.off;
+        T* dxo = ar.take<T>(n_xo);
+        out_begin = (size_t)((char*)dxo - (char*)h->d_stage);
+        T* duo = ar.take<T>(n_uo); T* dco = ar.take<T>(B);
+        int32_t* dam = ar.take<int32_t>(B); int32_t* dst = ar.take<int32_t>(B);
+        out_end = ar.off;
+        packed = bytes <= PACK_BYTES;
+        if (packed) {
+            char* hs = (char*)h->h_stage;
+            auto put = [&](const void* src, const void* d, size_t nbytes) {
+                std::memcpy(hs + ((const char*)d - (const char*)h->d_stage), src, nbytes);
+            };
+            put(x0, dx0, n_x * sizeof(T)); put(u_prev, dup, n_u * sizeof(T)); put(kparams, dk, n_k * sizeof(T));
+            put(flags, dfl, (size_t)B * 4);
+            if (n_obs) put(obs_xy, dob, n_obs * sizeof(T));
+            if (value) { put(tv_sv, dtv, n_u * sizeof(T)); put(enc, den, n_u * sizeof(T)); }
+            if (u_ws) put(u_ws, dws, n_uo * sizeof(T));
+            HIPCHK(hipMemcpyAsync(h->d_stage, hs, in_span, hipMemcpyHostToDevice, st));
+        } else {
+            if (value) {
+                HIPCHK(hipMemcpyAsync(dtv, tv_sv, n_u * sizeof(T), hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpyAsync(den, enc, n_u * sizeof(T), hipMemcpyHostToDevice, st));
+            }
+            if (u_ws) HIPCHK(hipMemcpyAsync(dws, u_ws, n_uo * sizeof(T), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dx0, x0, n_x * sizeof(T), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dup, u_prev, n_u * sizeof(T), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dk, kparams, n_k * sizeof(T), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dfl, flags, (size_t)B * 4, hipMemcpyHostToDevice, st));
+            if (n_obs) HIPCHK(hipMemcpyAsync(dob, obs_xy, n_obs * sizeof(T), hipMemcpyHostToDevice, st));
         }
         A.tv_sv = dtv; A.enc = den;
-        if (u_ws) {
-            T* dws = ar.take<T>(n_uo);
-            HIPCHK(hipMemcpyAsync(dws, u_ws, n_uo * sizeof(T), hipMemcpyHostToDevice, st));
-            A.u_ws = dws;
-        }
-        HIPCHK(hipMemcpyAsync(dx0, x0, n_x * sizeof(T), hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(dup, u_prev, n_u * sizeof(T), hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(dk, kparams, n_k * sizeof(T), hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(dfl, flags, (size_t)B * 4, hipMemcpyHostToDevice, st));
-        if (n_obs) HIPCHK(hipMemcpyAsync(dob, obs_xy, n_obs * sizeof(T), hipMemcpyHostToDevice, st));
+        if (u_ws) A.u_ws = dws;
         A.x0 = dx0; A.u_prev = dup; A.kparams = dk; A.flags = dfl; A.obs = dob;
         A.x_out = dxo; A.u_out = duo; A.cost_out = dco; A.argmin_out = dam; A.status_out = dst;
     } else {
@@ -363,7 +390,16 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
             if (FILE* f = std::fopen(path, "wb")) { std::fwrite(tr.data(), 8, n, f); std::fclose(f); }
         }
     }
-    if (mem == IGT_MEM_HOST) {
+    if (mem == IGT_MEM_HOST && packed) {
+        char* hs = (char*)h->h_stage;
+        HIPCHK(hipMemcpyAsync(hs + out_begin, (char*)h->d_stage + out_begin, out_end - out_begin, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        auto get = [&](void* dst_, const void* d, size_t nbytes) {
+            std::memcpy(dst_, hs + ((const char*)d - (const char*)h->d_stage), nbytes);
+        };
+        get(x_out, A.x_out, n_xo * sizeof(T)); get(u_out, A.u_out, n_uo * sizeof(T)); get(cost_out, A.cost_out, (size_t)B * sizeof(T));
+        get(argmin_out, A.argmin_out, (size_t)B * 4); get(status_out, A.status_out, (size_t)B * 4);
+    } else if (mem == IGT_MEM_HOST) {
         HIPCHK(hipMemcpyAsync(x_out, A.x_out, n_xo * sizeof(T), hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(u_out, A.u_out, n_uo * sizeof(T), hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(cost_out, A.cost_out, (size_t)B * sizeof(T), hipMemcpyDeviceToHost, st));
@@ -637,7 +673,7 @@ int igt_create(const igt_params* p, int device, igt_handle** out) {
     h->kp = make_kp(*p, 0);
     h->device = device;
     h->d_cinf = nullptr; h->d_table = nullptr; h->table_set = false; h->net_set = false;
-    h->d_stage = nullptr; h->stage_bytes = 0;
+    h->d_stage = nullptr; h->stage_bytes = 0; h->h_stage = nullptr;
     h->d_work = nullptr; h->work_bytes = 0;
     h->d_net = nullptr;
     h->d_routes = nullptr; h->n_routes = 0;
@@ -668,6 +704,7 @@ int igt_destroy(igt_handle* h) {
     if (h->d_cinf) (void)hipFree(h->d_cinf);
     if (h->d_table) (void)hipFree(h->d_table);
     if (h->d_stage) (void)hipFree(h->d_stage);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->d_work) (void)hipFree(h->d_work);
     if (h->d_net) (void)hipFree(h->d_net);
     if (h->d_routes) (void)hipFree(h->d_routes);
