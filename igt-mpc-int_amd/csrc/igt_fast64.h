@@ -208,7 +208,7 @@ struct Fast64 {
     // n_rk4 sub-steps of one control step.  The K == 0 variant (or the K == kv one) is taken when it is provably
     // exact for every active lane of the wave: straight route, or every lane's stage arguments stay outside (inside)
     // the arc [b0, b1] by the travel bound |ds| <= 2 |v| (1/(1 - K ey) < 2 for any state near the road).
-    // UNIFORM = false (emit: the lanes of a wave belong to different scenarios): general variant only.
+    // UNIFORM = false (emit: the lanes of a wave belong to different scenarios): the same choice by votes over the lanes.
     // the n_rk4 sub-steps of one variant; the reference's discretisation (4) is unrolled: no loop-carried register copies
     template <int MODE>
     __device__ __forceinline__ void run(const StepConst& sc, Work& w) const {
@@ -231,15 +231,14 @@ struct Fast64 {
         }
         sc.s2d = 2.0 * sc.sd * sc.cd; sc.c2d = fma(-2.0 * sc.sd, sc.sd, 1.0);
         ssc(hh * ((w.v1 + ha) * sblr), w.sh, w.ch);                  // h/2 w2 of the first sub-step
-        if (!UNIFORM) {
-            run<0>(sc, w);
-            return;
-        }
-        if (kv == 0.0) {                       // straight route: scalar condition, hoisted
+        // UNIFORM: kv is a scalar (one scenario per wave) and the straight-route test is hoisted; otherwise (emit: one
+        // scenario per lane) the whole-step decisions are taken by votes over the active lanes -- the variants are
+        // bit-identical where they apply
+        if (UNIFORM && kv == 0.0) {
             run<1>(sc, w);
             return;
         }
-        {   // the whole control step: |travel| <= 2 dt (|v| + dt |a|)
+        {   // the whole control step: |travel| <= 2 dt (|v| + dt |a|)   (a straight route's d0, d1 are -inf: clear)
             const double m = (2.0 * dt) * (fabs(w.v1) + dt * fabs(a));
             const bool clear = (w.d0 + m < 0.0) | (w.d1 - m > 0.0);
             const bool inside = (w.d0 - m > 0.0) & (w.d1 + m < 0.0);
@@ -251,6 +250,10 @@ struct Fast64 {
                 run<2>(sc, w);
                 return;
             }
+        }
+        if (!UNIFORM) {                        // lanes of different scenarios rarely agree sub-step by sub-step
+            run<0>(sc, w);
+            return;
         }
         for (int j = 0; j < n_rk4; ++j) {
             // travel bound of this sub-step: |o| <= h |ds| <= 2 h (|v| + |h a|)
@@ -354,7 +357,9 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
             if (k == P.N - 1) viol |= terminal_viol(P, v, a, cinf);                  // mpc.py:177-180
         }
         w.ey = ey; w.v1 = v;
-        if (fp.kv != 0.0) { w.d0 = s - fp.b0; w.d1 = s - fp.b1; }                    // unused on straight routes
+        // unused on straight routes; with one scenario per lane the votes of substeps() read them on every lane
+        // (a straight route's break-points are +inf: d = -inf, "clear")
+        if (!UNIFORM || fp.kv != 0.0) { w.d0 = s - fp.b0; w.d1 = s - fp.b1; }
         // (sin,cos)(epsi): heading errors beyond pi/4 are rare, the range reduction is skipped when no lane needs it
         if (__all(fabs(ep) < QUADRANT0)) sincos_kernel(ep, w.s1, w.c1);
         else sincos_reduced(ep, w.s1, w.c1);
