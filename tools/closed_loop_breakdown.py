@@ -11,13 +11,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'igt-mpc-int_amd'))
 import numpy as np
 from igtmpc.evaluate import run_closed_loop
+EPISODES = int(os.environ.get('IGT_CL_EPISODES', '64'))        # episodes per scenario
 cand = sys.argv[1] if len(sys.argv) > 1 else 'track'
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 C = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 RI = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 tot = dict(steps=0, infeasible=0, stopped=0, gridlock=0, stranded=0, cascade=0, first=0)
 for sc in range(1, 9):
-    r = run_closed_loop(sc=sc, num_samples=16, N=N, cand_mode=cand, dtype='f64', C=C, refine_iters=RI)
+    r = run_closed_loop(sc=sc, num_samples=EPISODES, N=N, cand_mode=cand, dtype='f64', C=C, refine_iters=RI)
     x, u = r['x_data'], r['u_data']                 # [E, 14, T+1], [E, 4, T]
     E, _, T = u.shape
     for m in range(2):

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Developer probe (GPU box): closed-loop statistics per scenario and candidate family (16 episodes x 150 steps each),
+"""Developer probe (GPU box): closed-loop statistics per scenario and candidate family (64 episodes x 150 steps (IGT_CL_EPISODES) each),
 with and without the warm start (previous solution shifted by one step as the centre of the ramp-hold candidates)."""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'igt-mpc-int_amd'))
 import numpy as np
 from igtmpc.evaluate import run_closed_loop
+EPISODES = int(os.environ.get('IGT_CL_EPISODES', '64'))        # episodes per scenario
 import itertools
 dtype = sys.argv[1] if len(sys.argv) > 1 else 'f64'
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 20          # horizon (mpc.yaml:6 ships 40; BASELINE fixes 20)
@@ -17,7 +18,7 @@ if len(sys.argv) > 3:                                       # only the configura
 tot = {}
 for cfg, sc in itertools.product(cfgs, range(1, 9)):
     (cm, ri, ws, ft), lim = cfg[:4], (cfg[4] if len(cfg) > 4 else None)
-    r = run_closed_loop(sc=sc, num_samples=16, N=N, cand_mode=cm, refine_iters=ri, warm_start=ws, dtype=dtype, feas_tol=ft, limits=lim)
+    r = run_closed_loop(sc=sc, num_samples=EPISODES, N=N, cand_mode=cm, refine_iters=ri, warm_start=ws, dtype=dtype, feas_tol=ft, limits=lim)
     row = {'cand': cm, 'limits': lim, 'refine': ri, 'warm': ws, 'feas_tol': ft, 'sc': sc, 'infeasible': r['infeasible_ratio'].mean(axis=0).round(3).tolist(),
            'deadlock': float(r['deadlock'].mean()), 'final_s': r['x_data'][:, 2::7, -1].mean(axis=0).round(1).tolist(),
            'max|ey|': float(np.abs(r['x_data'][:, 3::7, :]).max().round(3)),
