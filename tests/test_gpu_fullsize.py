@@ -43,14 +43,18 @@ def _net(golden_dir, sc):
     return layers
 
 
-def _check_subsample(b, got, idx, P, tol, eps, net=None):
+def _check_subsample(b, got, idx, P, tol, eps, net=None, cand='lattice'):
     """got[idx] against the float64 oracle on the same 512 scenarios."""
     f = lambda k: np.asarray(b[k][idx], dtype=np.float64)
     kw = {}
     if net is not None:
         kw = dict(net=net, tv_sv=f('tv_sv'), enc=f('enc'))
-    ref = O.solve_batch(f('x0'), f('u_prev'), f('kparams'), b['flags'][idx], f('obs_xy'), *_cinf(), P,
-                        return_all=True, **kw)
+    if cand == 'lattice':
+        ref = O.solve_batch(f('x0'), f('u_prev'), f('kparams'), b['flags'][idx], f('obs_xy'), *_cinf(), P,
+                            return_all=True, **kw)
+    else:
+        ref = O.solve_batch_refined(f('x0'), f('u_prev'), f('kparams'), b['flags'][idx], f('obs_xy'), *_cinf(), P,
+                                    cand=cand, **kw)[0]
     kp = f('kparams')[:, None, :]
     x0 = O.apply_flags(f('x0'), b['flags'][idx])[:, None, :]
     bp = O.breakpoint_distance(x0, ref['U'], kp, P)
@@ -59,7 +63,8 @@ def _check_subsample(b, got, idx, P, tol, eps, net=None):
     tie = eps if eps != F32_EPS else (2e-5 if net is not None else F32_TIE)
     amb = ambiguous_mask(ref, P, eps, tie, eps, bp)
     ok = ~amb
-    assert ok.mean() > 0.99, f'only {ok.mean():.3f} of the subsample is decided outside float noise'
+    # the steering feedback carries rounding differences forward: more of the tracking family's decisions sit inside noise
+    assert ok.mean() > (0.99 if cand == 'lattice' else 0.85), f'only {ok.mean():.3f} of the subsample is decided outside float noise'
     g = {k: got[k][idx] for k in ('x', 'u', 'cost', 'argmin', 'status')}
     assert (g['status'][ok] == ref['status'][ok]).all()
     assert (g['argmin'][ok] == ref['argmin'][ok]).all()
@@ -79,17 +84,17 @@ def _check_pieces(solver, b, big, cuts, extra=()):
         assert np.array_equal(np.concatenate([q[k] for q in parts]), big[k], equal_nan=True), k
 
 
-def _run(igt, B, offset, dtype, tol, eps, golden_dir=None, gt_sc=0):
+def _run(igt, B, offset, dtype, tol, eps, golden_dir=None, gt_sc=0, cand='lattice'):
     from igtmpc.scenarios import make_batch
     npdt = np.float64 if dtype == 'f64' else np.float32
     b = make_batch(B, dtype=npdt, offset=offset)
     assert set(np.unique(b['sc'])) == set(range(1, 9)), 'all 8 scenario variants must be tiled into the batch'
     idx = np.sort(np.random.default_rng(7).choice(B, 512, replace=False))
-    kw, extra, net = {}, (), None
+    kw, extra, net = dict(cand_mode=cand), (), None
     if gt_sc:
         layers = _net(golden_dir, gt_sc)
         net = dict(layers=layers, Wn=np.eye(6), mu_f=np.zeros(6), sigma_t=1.0, mu_t=0.0)   # bench.py's normalisation
-        kw = dict(cost_mode='value_net')
+        kw['cost_mode'] = 'value_net'
         extra = ('tv_sv', 'enc')
     with igt.BatchSolver(dtype=dtype, **kw) as s:
         P = oracle_params(s)
@@ -100,8 +105,8 @@ def _run(igt, B, offset, dtype, tol, eps, golden_dir=None, gt_sc=0):
         assert 0.5 < (big['status'] == 0).mean() < 1.0
         q = B // 4
         _check_pieces(s, b, big, [0, 4096, 4096 + 1003, q + 17, 2 * q, 3 * q + 5, B], extra)
-    amb = _check_subsample(b, big, idx, P, tol, eps, net)
-    print(f'B={B} dtype={dtype} gt={gt_sc}: ambiguous share of the subsample {amb:.4f}')
+    amb = _check_subsample(b, big, idx, P, tol, eps, net, cand)
+    print(f'B={B} dtype={dtype} gt={gt_sc} cand={cand}: ambiguous share of the subsample {amb:.4f}')
 
 
 @pytest.mark.parametrize('dtype,tol,eps', [('f64', 1e-9, 1e-9), ('f32', REL_TOL, F32_EPS)])
@@ -122,3 +127,11 @@ def test_config4_gt_mpc_65536(igt, golden_dir, dtype, tol, eps, sc):
     """BASELINE configs[4]: gt_mpc, terminal value network (shipped V_GT_sc1: 2 hidden layers, V_GT_sc3: 3) evaluated
     on the GPU inside the cost, batch = 65 536 (per GPU; the 8-GPU run itself is the driver's)."""
     _run(igt, 65536, 0, dtype, tol, eps, golden_dir, sc)
+
+
+@pytest.mark.parametrize('dtype,tol,eps', [('f64', 1e-9, 1e-9), ('f32', REL_TOL, 2e-5)])
+def test_config2_batch_65536_tracking_family(igt, dtype, tol, eps):
+    """The same full-size batch through the family the planner and the closed-loop driver use by default
+    (IGT_CAND_TRACK: steering feedback inside the roll-out, acceleration envelope): oracle on the 512-scenario subsample
+    + the big batch equals the same scenarios solved in pieces, bitwise."""
+    _run(igt, 65536, 0, dtype, tol, eps, cand='track')
