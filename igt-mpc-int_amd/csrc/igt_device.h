@@ -23,7 +23,7 @@ struct KP {  // kernel parameters (by value -> SGPRs)
     int N, n_rk4, C, n_obs, cand_mode, cost_mode, F, G, hi_order, refine_it;
     int df_small;   // df_max < pi/4: generated steering angles need no range reduction
     // developer switches (env IGT_DEV_FLAGS; A/B measurements only, results do not depend on them):
-    //   1 slices along the acceleration axis, 2 no early exit, 8 / 32 force 2 / 3 search waves per SIMD,
+    //   1 slices along the acceleration axis, 2 no early exit, 4 no steering table (f64 search), 8 / 32 force 2 / 3 search waves per SIMD,
     //   16 no longest-first queue order, 256 unit trace (with IGT_DEV_TRACE=<file>), 512 no stealing between queues,
     //   bits 12-15: items per wave at the end of a queue whose index is fetched late (default 4)
     int dev;

@@ -274,10 +274,65 @@ struct Fast64 {
 // CAND_TABLE: controls come from the table and are checked.  BOOK = false (emit): cost and verdicts are skipped.
 // EARLY_EXIT (search): the unit stops once every candidate of the wave has failed a verdict; then only "failed" is
 // reported (vout != 0), the verdict bits are those found so far.
-template <int CAND, bool HI_ORDER, bool BOOK, bool UNIFORM, class Sink, bool EARLY_EXIT = false>
+// Steering angle of step k for the generated families whose steering does not depend on the rolled state.
+template <int CAND>
+__device__ __forceinline__ double steer_next(const KP& P, const Scenario<double>& S, int k, double ddf, double df) {
+    if (CAND == CAND_LATTICE) return clampd(df + ddf, -P.df_max, P.df_max);
+    double ba, bdf;                                                   // CAND_RAMP_HOLD
+    ramp_base<double>(S.ws, P.N, k, S.a_prev, S.df_prev, ba, bdf);
+    const double tdf = clampd(bdf + ddf, -P.df_max, P.df_max);
+    return clampd(df + clampd(tdf - df, -P.rate_df, P.rate_df), -P.df_max, P.df_max);
+}
+// ddf of steering column j (lattice increment / ramp-hold target offset) -- as rollout_one derives it from the candidate
+template <int CAND>
+__device__ __forceinline__ double steer_column(const KP& P, const Scenario<double>& S, int j) {
+    if (CAND == CAND_LATTICE) return -P.rate_df + (2 * P.rate_df) * (double)j / (double)(P.G - 1);
+    return S.cpar[1] + cand_m(j, P.G, P.refine_it == 0) * S.cpar[3];
+}
+// (sin, cos) of the slip angle beta = atan(r tan df), r = l_r/(l_f+l_r):  cos = c/n, sin = r s/n, n = sqrt(c^2 + r^2 s^2)
+template <int CAND>
+__device__ __forceinline__ void slip_trig(const KP& P, double lr_ratio, double df, double& sb, double& cb) {
+    double sdf, cdf;
+    if (CAND != CAND_TABLE && P.df_small) sincos_kernel(df, sdf, cdf);       // |df| <= df_max < pi/4
+    else sincos_reduced(df, sdf, cdf);
+    const double n = rsq_nr(fma((lr_ratio * lr_ratio) * sdf, sdf, cdf * cdf));   // argument in [r^2, 1]
+    cb = cdf * n;
+    sb = lr_ratio * sdf * n;
+}
+// Steering table of one search unit (lattice, ramp-hold): the lanes of a 64-candidate steering slice share G/W steering
+// columns, each rolled by 64 W/G lanes with the same (df_k, sin beta_k, cos beta_k) -- ~50 instructions per lane and
+// step that depend on nothing but the column.  The unit's wave lays the columns out once in LDS, [k][column][df, sin,
+// cos] (the angles sequentially on one lane per column -- the recursion is the candidates' own -- then the trigonometry
+// of all entries in parallel), with the same functions the untabulated roll-out calls: the same bits.
+constexpr int STAB_MAX_ENTRIES = 320;        // columns x N per unit (C = 256: 4 x 20, N = 40: 160; C = 64: 8 x 40)
+template <int CAND>
+__device__ __forceinline__ void fill_steer_table(const KP& P, const Scenario<double>& S, int nj, int p, int lane,
+                                                 double lr_ratio, double* __restrict__ stab) {
+    if (lane < nj) {
+        const int r = p * nj + lane;
+        const int j = (r & 1) ? P.G / 2 - 1 - (r >> 1) : P.G / 2 + (r >> 1);      // slice_candidate64's column order
+        const double ddf = steer_column<CAND>(P, S, j);
+        double df = S.df_prev;
+        for (int k = 0; k < P.N; ++k) {
+            df = steer_next<CAND>(P, S, k, ddf, df);
+            stab[(k * nj + lane) * 3] = df;
+        }
+    }
+    __syncthreads();
+    for (int e = lane; e < nj * P.N; e += 64) {
+        double sb, cb;
+        slip_trig<CAND>(P, lr_ratio, stab[e * 3], sb, cb);
+        stab[e * 3 + 1] = sb;
+        stab[e * 3 + 2] = cb;
+    }
+    __syncthreads();
+}
+
+template <int CAND, bool HI_ORDER, bool BOOK, bool UNIFORM, class Sink, bool EARLY_EXIT = false, bool STAB = false>
 __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>& S, int cidx,
                                             const double* __restrict__ table, const double* __restrict__ cinf,
-                                            Sink& sink, double& Jout, unsigned& vout, double& sN, double& vN) {
+                                            Sink& sink, double& Jout, unsigned& vout, double& sN, double& vN,
+                                            const double* __restrict__ stab = nullptr, int stab_stride = 0) {
     constexpr bool KEEP_PSI = Sink::kKeepsStates;
     // search only needs feasible-or-not: |ey|, box v and collision are folded into one running maximum, compared with
     // the tolerance when it is read (x > tol for some x  <=>  max x > tol; a NaN operand is ignored by both forms)
@@ -289,12 +344,11 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
     double a = S.a_prev, df = S.df_prev, da = 0.0, ddf = 0.0, J = 0.0, gmax = -1.0e300;
     unsigned viol = 0;
     bool dead = false;
-    const double ratio2 = fp.lr_ratio * fp.lr_ratio;
     if (CAND == CAND_LATTICE) {
         // da_i = -ra + (2 ra) i/(G-1), ddf_j likewise (oracle candidates_lattice)
         const int i = cidx / P.G, j = cidx - i * P.G;
         da = -P.rate_a + (2 * P.rate_a) * (double)i / (double)(P.G - 1);
-        ddf = -P.rate_df + (2 * P.rate_df) * (double)j / (double)(P.G - 1);
+        ddf = steer_column<CAND>(P, S, j);
     } else if (CAND == CAND_RAMP_HOLD || CAND == CAND_TRACK) {
         // da / ddf hold the OFFSETS of the targets from the base sequence here (igt_device.h cand_m, ramp_base);
         // CAND_TRACK: ddf is the slip-angle offset of the steering feedback (track_steer)
@@ -312,13 +366,13 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
         // ---- controls of step k
         if (CAND == CAND_LATTICE) {
             a = clampd(a + da, P.a_min, P.a_max);
-            df = clampd(df + ddf, -P.df_max, P.df_max);
+            df = STAB ? stab[k * stab_stride] : steer_next<CAND>(P, S, k, ddf, df);
         } else if (CAND == CAND_RAMP_HOLD) {
             double ba, bdf;
             ramp_base<double>(S.ws, P.N, k, S.a_prev, S.df_prev, ba, bdf);
-            const double ta = clampd(ba + da, P.a_min, P.a_max), tdf = clampd(bdf + ddf, -P.df_max, P.df_max);
+            const double ta = clampd(ba + da, P.a_min, P.a_max);
             a = clampd(a + clampd(ta - a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
-            df = clampd(df + clampd(tdf - df, -P.rate_df, P.rate_df), -P.df_max, P.df_max);
+            df = STAB ? stab[k * stab_stride] : steer_next<CAND>(P, S, k, ddf, df);
         } else if (CAND == CAND_TRACK) {
             double ba, bdf;
             ramp_base<double>(S.ws, P.N, k, S.a_prev, S.df_prev, ba, bdf);
@@ -335,12 +389,13 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
             a = an; df = dn;
         }
         sink.ctrl(0, k, a, df);
-        // beta = atan(r tan df), r = l_r/(l_f+l_r):  cos(beta) = c/n, sin(beta) = r s/n, n = sqrt(c^2 + r^2 s^2)
-        double sdf, cdf;
-        if (CAND != CAND_TABLE && P.df_small) sincos_kernel(df, sdf, cdf);       // |df| <= df_max < pi/4
-        else sincos_reduced(df, sdf, cdf);
-        const double n = rsq_nr(fma(ratio2 * sdf, sdf, cdf * cdf));                  // argument in [r^2, 1]
-        const double cb = cdf * n, sb = fp.lr_ratio * sdf * n;
+        double sb, cb;                               // (sin, cos)(beta), beta = atan(r tan df)
+        if (STAB && (CAND == CAND_LATTICE || CAND == CAND_RAMP_HOLD)) {
+            sb = stab[k * stab_stride + 1];
+            cb = stab[k * stab_stride + 2];
+        } else {
+            slip_trig<CAND>(P, fp.lr_ratio, df, sb, cb);
+        }
         const double sblr = sb * fp.inv_lr;
         // ---- bookkeeping of state k (cost in the oracle's order: control effort, epsi^2, ey^2 -- mpc.py:361-364)
         if (BOOK) {

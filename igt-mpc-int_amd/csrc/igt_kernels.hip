@@ -730,7 +730,19 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
     const int c = slice_candidate64<CAND>(P, W, p, lane);
     double J, sN, vN;
     unsigned viol;
-    f64::rollout_one<CAND, HI, true, true, NullSink, true>(P, S, c, table, cinf, sink, J, viol, sN, vN);
+    // steering slices of the families with state-independent steering: the slice's G/W steering columns are laid out in
+    // LDS once per unit instead of being recomputed by each of their 64 W/G lanes at every step (igt_fast64.h)
+    constexpr bool TABULATED = CAND == CAND_LATTICE || CAND == CAND_RAMP_HOLD;
+    const int nj = P.G / W;
+    if (TABULATED && steering_slices64<CAND>(P, W) && nj * P.N <= f64::STAB_MAX_ENTRIES && !(P.dev & 4)) {
+        __shared__ double stab[f64::STAB_MAX_ENTRIES * 3];
+        f64::fill_steer_table<CAND>(P, S, nj, p, lane, P.lr_ratio, stab);
+        f64::rollout_one<CAND, HI, true, true, NullSink, true, true>(P, S, c, table, cinf, sink, J, viol, sN, vN,
+                                                                     stab + (lane % nj) * 3, nj * 3);
+        __syncthreads();                                  // the next unit of this wave rewrites the table
+    } else {
+        f64::rollout_one<CAND, HI, true, true, NullSink, true>(P, S, c, table, cinf, sink, J, viol, sN, vN);
+    }
     if (VALUE) {   // terminal value network (mpc.py:369): append the feasible candidates for value_mfma_f64_kernel; the
                    // unit's entries are contiguous, unit_seg remembers where (unit_reduce_kernel picks the unit's best)
         const bool ok = viol == 0 && finite_d(J);
