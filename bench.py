@@ -197,7 +197,7 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip the other-precision block')
     ap.add_argument('--gt', type=int, default=0, metavar='SC',
                     help='gt_mpc cost with the shipped value net of scenario SC (1 or 3; BASELINE configs[4]); 0 = mpc cost')
-    ap.add_argument('--in-flight', type=int, default=4, choices=[1, 2, 3, 4],
+    ap.add_argument('--in-flight', type=int, default=4, choices=[1, 2, 3, 4, 5, 6, 8],
                     help='solves in flight: step t runs on handle/stream t mod F (each handle owns its workspace and '
                          'output buffers), so the emit pass and the drain tail of one step overlap the search pass of the next')
     ap.add_argument('--rehearse-cpu', action='store_true', help=argparse.SUPPRESS)
