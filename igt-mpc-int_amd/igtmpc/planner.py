@@ -189,11 +189,11 @@ class MPC_Planner:
         evaluate per candidate (progress cost; the value-net term lives on the device only)."""
         x, u = np.asarray(x, dtype=np.float64), np.asarray(u, dtype=np.float64)
         J = 0.0
-        for k in range(self.N + 1):
-            if k < self.N:
-                J = J + 0.05 * (u[0, k] ** 2 + u[1, k] ** 2)           # mpc.py:362
-            J = J + x[4, k] ** 2                                        # mpc.py:363
-            J = J + x[3, k] ** 2                                        # mpc.py:364
+        for k in range(self.N + 1):      # squares as products: what casadi's sq() and the kernels evaluate (a numpy
+            if k < self.N:               # SCALAR ** 2 goes through libm pow(), one ulp off for ~1 value in 10^4)
+                J = J + 0.05 * (u[0, k] * u[0, k] + u[1, k] * u[1, k])  # mpc.py:362
+            J = J + x[4, k] * x[4, k]                                   # mpc.py:363
+            J = J + x[3, k] * x[3, k]                                   # mpc.py:364
         return J - (x[2, self.N] - x[2, 0])                             # mpc.py:372
 
     def cost_function(self):
