@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -58,6 +59,7 @@ struct igt_handle {
     int n_cu;              // compute units of the device (sizes the persistent search grid)
     void* comm;            // RCCL communicator of igt_comm_init (null: none)
     int comm_world, comm_rank;
+    int32_t comm_B_local;  // shard size of the communicator's first all-gather (0 = none yet); later calls must match
     void* d_u0;            // [B_local,2] first-step controls staged for the all-gather
     size_t u0_bytes;
 };
@@ -77,9 +79,8 @@ struct Rccl {
 };
 Rccl* rccl() {
     static Rccl r;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;          // handles are per thread-group; two of them may reach igt_comm_* together
+    std::call_once(once, [] {
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names)
             if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;          // one the process already mapped
@@ -92,7 +93,7 @@ Rccl* rccl() {
             r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
             if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) r.lib = nullptr;
         }
-    }
+    });
     return r.lib ? &r : nullptr;
 }
 int rccl_fail(Rccl* r, const char* what, int rc) {
@@ -150,7 +151,10 @@ igt::KP make_kp(const igt_params& p, int F) {
     k.trk_ke = p.track_ke; k.trk_span = p.track_span; k.trk_blim = p.track_beta_lim;
     // slope of the acceleration envelope (igt_device.h track_accel_target); products and one quotient only, so the
     // oracle's track_env_slope() gives the same bits
-    k.trk_env = (p.track_env > 0 && p.w_u > 0) ? p.track_env * p.dt * p.dt / (2 * p.w_u) : (double)INFINITY;
+    // The envelope is the stationary point of  w_u a_k^2 - (s_N - s_0)  (mpc.py:362, 372).  The gt_mpc cost has no
+    // progress term (mpc.py:367-370: the value network stands there), so with IGT_COST_VALUE_NET it is not applied.
+    k.trk_env = (p.track_env > 0 && p.w_u > 0 && p.cost_mode == IGT_COST_PROGRESS)
+                    ? p.track_env * p.dt * p.dt / (2 * p.w_u) : (double)INFINITY;
     // stage-offset polynomials: short form while h * (largest angular rate a candidate can reach) stays
     // small (igt_fast.h small_sincos2); v up to v_max + 2, |K| up to 0.25, sin(beta)/l_r <= 0.7/l_r
     const double vhi = std::fmax(std::fabs(p.v_min), std::fabs(p.v_max)) + 2.0;
@@ -609,14 +613,23 @@ template <typename T>
 int allgather_impl(igt_handle* h, int32_t B_local, const T* u_out, T* u0_all, void* stream) {
     if (!h) return fail(IGT_E_INVALID, "null handle");
     if (B_local < 0) return fail(IGT_E_INVALID, "B_local < 0");
-    if (B_local == 0) return IGT_OK;
+    if (!h->comm) {         // no communicator = one shard: the gathered vector is the local one
+        if (B_local == 0) return IGT_OK;
+        if (!u_out || !u0_all) return fail(IGT_E_INVALID, "null buffer");
+        HIPCHK(hipSetDevice(h->device));
+        hipStream_t st0 = stream ? (hipStream_t)stream : h->stream;
+        HIPCHK(igt::launch_first_controls<T>(B_local, h->p.N, u_out, u0_all, st0));
+        return IGT_OK;
+    }
+    // With a communicator every rank enters ncclAllGather with the SAME count or the peers hang / read garbage: an
+    // empty shard is refused (pad it, as the header says), and the count of the first call is the communicator's.
+    if (B_local == 0) return fail(IGT_E_INVALID, "B_local == 0 with a communicator: every rank must take part with the same padded B_local");
+    if (h->comm_B_local == 0) h->comm_B_local = B_local;
+    else if (h->comm_B_local != B_local)
+        return fail(IGT_E_INVALID, "B_local changed since the communicator's first all-gather (all ranks must pass one padded shard size)");
     if (!u_out || !u0_all) return fail(IGT_E_INVALID, "null buffer");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    if (!h->comm) {         // no communicator = one shard: the gathered vector is the local one
-        HIPCHK(igt::launch_first_controls<T>(B_local, h->p.N, u_out, u0_all, st));
-        return IGT_OK;
-    }
     const size_t bytes = (size_t)B_local * 2 * sizeof(T);
     if (bytes > h->u0_bytes) {
         if (capturing(st)) return fail(IGT_E_STATE, "staging buffer too small for stream capture: run one eager call first");
@@ -678,7 +691,7 @@ int igt_create(const igt_params* p, int device, igt_handle** out) {
     h->d_net = nullptr;
     h->d_routes = nullptr; h->n_routes = 0;
     h->prof = false; h->ev_recorded = false;
-    h->comm = nullptr; h->comm_world = 1; h->comm_rank = 0; h->d_u0 = nullptr; h->u0_bytes = 0;
+    h->comm = nullptr; h->comm_world = 1; h->comm_rank = 0; h->comm_B_local = 0; h->d_u0 = nullptr; h->u0_bytes = 0;
     h->nc = 2;
     if (const char* e = std::getenv("IGT_NC")) {
         const int v = std::atoi(e);
@@ -999,7 +1012,7 @@ int igt_comm_init(igt_handle* h, int32_t world, int32_t rank, const void* id) {
     std::memcpy(nid.internal, id, IGT_COMM_ID_BYTES);
     void* comm = nullptr;
     if (int rc = r->CommInitRank(&comm, world, nid, rank)) return rccl_fail(r, "ncclCommInitRank", rc);
-    h->comm = comm; h->comm_world = world; h->comm_rank = rank;
+    h->comm = comm; h->comm_world = world; h->comm_rank = rank; h->comm_B_local = 0;
     return IGT_OK;
 }
 
@@ -1009,7 +1022,7 @@ int igt_comm_destroy(igt_handle* h) {
     Rccl* r = rccl();
     HIPCHK(hipSetDevice(h->device));
     const int rc = r ? r->CommDestroy(h->comm) : 0;
-    h->comm = nullptr; h->comm_world = 1; h->comm_rank = 0;
+    h->comm = nullptr; h->comm_world = 1; h->comm_rank = 0; h->comm_B_local = 0;
     return rc ? rccl_fail(r, "ncclCommDestroy", rc) : IGT_OK;
 }
 

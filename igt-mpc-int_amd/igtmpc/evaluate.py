@@ -6,6 +6,8 @@ predictions -- a Jacobi update, evaluate.py:469-558 -- so batching changes nothi
 Kept from the reference, with citations:
   * initial states: random offset along the approach lane, v0 = 0, s = offset      (evaluate.py:91-94, 404-418)
   * previous inputs start at (0.1, 0)                                               (evaluate.py:419)
+  * gt_mpc: previous inputs start at (0, 0) (:171); the first forecast uses a = 0.09 (k+1) for agent k (:207-210);
+    the warm start is passed for t > 1 only (:232; the mpc branch passes it from t = 1, :478)
   * per step: predict -> share motion forecasts (V2V) -> filter_preds -> solve      (evaluate.py:455-482)
   * solved: next state = x*[:,1], applied input = u*[:,0]                           (evaluate.py:491-510)
   * infeasible: brake a = a_min (if v > 0 else 0), keep df, one model step; v < 0 -> stop  (evaluate.py:511-545)
@@ -136,7 +138,7 @@ def run_closed_loop(sc=1, num_samples=1, N=40, dt=0.1, T_sim=15.0, seed=2026, C=
         #     step passes that solution, shifted by one step, as its warm start (evaluate.py:478-481)
         t0 = time.perf_counter()
         fl, u_ws = flags, None
-        if warm and t > 0:
+        if warm and t > (1 if gt else 0):                              # evaluate.py:478 (mpc: t >= 1) / :232 (gt_mpc: t > 1)
             fl = flags | np.where(have_sol.reshape(-1), IGT_FLAG_WARM, 0).astype(np.uint32)
             u_ws = shift_controls(sol_u).reshape(E * M, 2, N).astype(npdt)
         out = solver.solve(x.reshape(E * M, 7).astype(npdt), u_prev.reshape(E * M, 2).astype(npdt),
@@ -209,7 +211,7 @@ def _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc, gt, E, M, N, M
     col = torch.zeros(1, dtype=torch.int64, device=dev)            # the step the next call of step() computes
     a_fc0 = torch.as_tensor(0.09 * (np.arange(M)[::-1] + 1.0), device=dev).expand(E, M) if gt else None
 
-    def step(first):
+    def step(first, warm_ok=True):
         xo, uo = x.flip(1), u_prev.flip(1)
         a_fc = a_fc0 if (gt and first) else uo[..., 0]
         hp = (have_sol.flip(1) & (not first)).reshape(-1).to(torch.int32).contiguous()
@@ -219,7 +221,7 @@ def _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc, gt, E, M, N, M
                                   sol_x.flip(1).reshape(E * M, 7, N + 1).contiguous(),
                                   sol_u.flip(1).reshape(E * M, 2, N).contiguous(), hp)
         fl, u_ws = flags_t, None
-        if warm and not first:
+        if warm and not first and warm_ok:
             fl = flags_t | (have_sol.reshape(-1).to(torch.int32) * IGT_FLAG_WARM)
             u_ws = shift_controls(sol_u).reshape(E * M, 2, N).contiguous()
         out = solver.solve(x.reshape(E * M, 7).to(td).contiguous(), u_prev.reshape(E * M, 2).to(td).contiguous(), kp_s,
@@ -253,11 +255,15 @@ def _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc, gt, E, M, N, M
     t_start = time.perf_counter()
     step(True)
     t = 1
-    if graph and M_sim > 3:
+    use_graph = graph and M_sim > 3
+    if gt and not use_graph and M_sim > 1:
+        step(False, warm_ok=False)             # evaluate.py:232: the gt_mpc loop passes its warm start for t > 1 only
+        t = 2
+    if use_graph:
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            step(False)                        # warm-up of the generic step on the capture stream (workspaces are sized now)
+            step(False, warm_ok=not gt)        # step 1, eagerly, on the capture stream (gt_mpc: no warm start yet, :232)
         torch.cuda.current_stream(dev).wait_stream(side)
         t = 2
         g = torch.cuda.CUDAGraph()

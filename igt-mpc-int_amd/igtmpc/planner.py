@@ -7,17 +7,67 @@ per (scenario, ego) problem on the MI355X) and returns the feasible arg-min of t
 Planners created with the same discretisation share one solver handle per device; the batched
 entry (`BatchSolver.solve`) is the throughput path, this class is the per-agent compatibility face.
 """
+import atexit
 import hashlib
+import os
+import re
 import time
+import warnings
 
 import numpy as np
 
 from .cinf import cinf_halfplanes
 from ._lib import IGT_FLAG_WARM
 from .solver import BatchSolver
+from .value_nets import shipped_value_net
 from .vehicle import Curvature, VehicleAction, VehicleReference  # noqa: F401  (re-exported for drivers)
 
 _SHARED = {}
+
+
+@atexit.register
+def close_shared_solvers():
+    """Planners share solver handles (one per configuration); they are destroyed here, once, at interpreter exit --
+    or earlier by a driver that is done with its planners."""
+    while _SHARED:
+        _SHARED.popitem()[1].close()
+
+
+def value_net_from_config(nn_config_dir):
+    """What mpc.py:72-74, 108-124 does with `nn_config_dir` (evaluate.py:191 passes get_scenario_config(sc) =
+    <cwd>/game_theoretic_NN/configs/sc{n}_config.yaml): read the YAML, build mlp(6, 1, [hidden_size]*num_layers, tanh)
+    and load `model_path`.  Here: the scenario number is taken from the YAML's model_path (V_GT_sc{n}.pt) or, when the
+    file is not there, from the path's own name (sc{n}_config); a checkpoint found at <cwd> + model_path is read with
+    torch.load(weights_only=True), otherwise the weights shipped with this package are used (the same eight networks).
+    The feature / target statistics (mpc.py:110-118) live in a dataset pickle the reference does not ship: identity
+    whitening is used and a warning says so.  -> (value_net dict for BatchSolver.set_value_net, include_route)."""
+    cfg = None
+    if os.path.isfile(nn_config_dir):
+        import yaml
+        with open(nn_config_dir) as f:
+            cfg = yaml.safe_load(f) or {}
+    m = re.search(r'V_GT_sc(\d+)', str((cfg or {}).get('model_path', ''))) or \
+        re.search(r'sc(\d+)_config', os.path.basename(str(nn_config_dir)))
+    if m is None:
+        raise ValueError(f'nn_config_dir={nn_config_dir!r}: neither a readable sc<n>_config.yaml nor a path that names one')
+    sc = int(m.group(1))
+    layers = None
+    ckpt = os.getcwd() + str((cfg or {}).get('model_path', ''))             # mpc.py:124
+    if cfg and os.path.isfile(ckpt):
+        import torch
+        sd = torch.load(ckpt, map_location='cpu', weights_only=True)
+        keys = sorted((k for k in sd if k.endswith('weight')), key=lambda k: int(k.split('.')[1]))
+        layers = [(sd[k].double().numpy(), sd[k.replace('weight', 'bias')].double().numpy()) for k in keys]
+    net = dict(layers=layers) if layers is not None else shipped_value_net(sc)
+    if cfg:
+        n_hidden, width = len(net['layers']) - 1, net['layers'][0][0].shape[0]
+        if int(cfg.get('num_layers', n_hidden)) != n_hidden or int(cfg.get('hidden_size', width)) != width:
+            raise ValueError(f'{nn_config_dir}: hidden_size / num_layers do not describe the scenario-{sc} network '
+                             f'({n_hidden} hidden layers of {width})')
+    warnings.warn('gt_mpc value network: the feature / target normalisation statistics (mpc.py:110-118) come from a '
+                  'dataset the reference does not ship; identity statistics are used (pass value_net=dict(layers, Wn, '
+                  'mu_f, sigma_t, mu_t) to supply them)', stacklevel=3)
+    return net, bool((cfg or {}).get('include_route', False))
 
 
 def _net_digest(value_net):
@@ -99,6 +149,13 @@ class MPC_Planner:
         self.C_inf = cinf_halfplanes(dt=dt, jerk=self.jerk_limit)
         cost_mode = 'value_net' if use_NN_cost2go else 'progress'
         self.cand_mode = cand_mode
+        include_route = False
+        if use_NN_cost2go and value_net is None:
+            if nn_config_dir is None:
+                raise ValueError('use_NN_cost2go=True needs nn_config_dir (the reference\'s call, evaluate.py:191) or '
+                                 'value_net=dict(layers[, Wn, mu_f, sigma_t, mu_t])')
+            value_net, include_route = value_net_from_config(nn_config_dir)     # mpc.py:72-74, 108-124
+        self.NN_config = dict(include_route=include_route) if use_NN_cost2go else None
         # planners with the same discretisation, candidate family and value network share one solver handle; the
         # network is keyed by CONTENT (a dict rebuilt with the same weights maps to the same handle)
         key = (N, dt, num_rk4_steps, C, self.num_obstacles, device, dtype, cost_mode, self.d_min, cand_mode, refine_iters,
@@ -109,9 +166,6 @@ class MPC_Planner:
                             refine_iters=refine_iters)
             s.set_cinf(*self.C_inf)
             if use_NN_cost2go:
-                if value_net is None:
-                    raise ValueError('use_NN_cost2go=True needs value_net=dict(layers, Wn, mu_f, sigma_t, mu_t): the '
-                                     "reference's normalisation statistics live in a dataset that is not shipped")
                 s.set_value_net(**value_net)
             _SHARED[key] = s
         self._solver = _SHARED[key]
@@ -122,8 +176,11 @@ class MPC_Planner:
         self._tv_sv = np.zeros((1, 2), self._dt)
         self._enc = np.zeros((1, 2), self._dt)
         if use_NN_cost2go:
-            from .routes import scenario_encoding_sign, scenario_of
-            e = scenario_encoding_sign(list(routes), scenario_of(list(routes)))      # mpc.py:336-337
+            from .routes import ROUTE_ID, scenario_encoding_sign, scenario_of
+            if include_route:
+                e = [ROUTE_ID[r] for r in routes]                                    # mpc.py:332-334, utils.py:393-402
+            else:
+                e = scenario_encoding_sign(list(routes), scenario_of(list(routes)))  # mpc.py:336-337
             j = self.pred_ind[0]
             self._enc[0] = (e[index], e[j])
         self.update_initial_condition(self.initial_agent, VehicleAction({'a': 0.0, 'df': 0.0}))

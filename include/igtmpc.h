@@ -113,7 +113,9 @@ typedef struct igt_params {
     double track_ke;         /* IGT_CAND_TRACK: lateral-error gain of the steering feedback [1/m]          (0.3)  */
     double track_span;       /* IGT_CAND_TRACK: the G slip-angle offsets span +-track_span [rad]            (0.1)  */
     double track_beta_lim;   /* IGT_CAND_TRACK: |beta_cmd| limit [rad]                                      (0.7)  */
-    double track_env;        /* IGT_CAND_TRACK: scale of the acceleration envelope E_k; 0 = no envelope     (1.0)  */
+    double track_env;        /* IGT_CAND_TRACK: scale of the acceleration envelope E_k; 0 = no envelope     (1.0)
+                                Applied with IGT_COST_PROGRESS only: E_k is derived from the progress term
+                                (mpc.py:372), which the IGT_COST_VALUE_NET cost does not have (mpc.py:367-370) */
 } igt_params;
 
 /* Fills *p with the reference's numbers: N=20, dt=0.1, n_rk4=4, C=256, n_obs=1,
@@ -275,8 +277,11 @@ int igt_cartesian_euler_f64(igt_handle* h, int32_t n, int32_t T, const double* z
  *   igt_comm_unique_id : rank 0 creates the 128-byte id; the caller distributes it (MPI_Bcast, a file, a socket).
  *   igt_comm_init      : every rank, same id; one communicator per handle.
  *   igt_allgather_controls_* : u_out [B_local,2,N] (device) -> u0_all [world*B_local,2] (device), rank-major, enqueued
- *                        on `stream`.  Equal shards (ncclAllGather); ragged shards are padded by the caller.  Without a
- *                        communicator (world = 1) it reduces to the strided copy u0_all = u_out[:, :, 0]. */
+ *                        on `stream`.  Equal shards (ncclAllGather); ragged shards are padded by the caller: with a
+ *                        communicator EVERY rank must call with the same B_local > 0 -- an empty shard or a size
+ *                        that differs from the communicator's first call returns IGT_E_INVALID instead of leaving the
+ *                        peers waiting inside the collective.  Without a communicator (world = 1) it reduces to the
+ *                        strided copy u0_all = u_out[:, :, 0] (B_local = 0: nothing to do). */
 #define IGT_COMM_ID_BYTES 128
 int igt_comm_unique_id(void* id_out /* IGT_COMM_ID_BYTES */);
 int igt_comm_init(igt_handle* h, int32_t world, int32_t rank, const void* id);

@@ -1,9 +1,9 @@
 """
 TEST INFRASTRUCTURE ONLY -- float64 restatement of the reference's closed-loop time loop.
 
-Restates evaluate.py:451-569 (--eval_mode mpc) for ONE episode at a time, agent by agent, in plain Python with the
-reference's own variable roles, so that igtmpc/evaluate.py (E episodes in lock-step, batched, on the GPU) has something
-independent to be compared with:
+Restates evaluate.py:451-569 (--eval_mode mpc) and evaluate.py:202-330 (--eval_mode gt_mpc) for ONE episode at a time,
+agent by agent, in plain Python with the reference's own variable roles, so that igtmpc/evaluate.py (E episodes in
+lock-step, batched, on the GPU) has something independent to be compared with:
 
     for t in range(M_sim):                                                        evaluate.py:451
         preds      = predictor.predict(cur states, prev inputs)                   :455   (np_oracle.predict_constant_accel)
@@ -17,6 +17,15 @@ independent to be compared with:
             else: brake a = a_min if v > 0 else 0, keep df, one model step;       :511-545
                   v < 0: applied a = 0, state frozen with v = 0                   :523-526
     deadlock = at least two agents end with s <= 30                               :566-569
+
+What the gt_mpc branch does differently (eval_mode='gt_mpc'):
+    previous inputs start at (0, 0), not (0.1, 0)                                 evaluate.py:171 vs 419
+    t == 0: the forecast is made with a = 0.09 (k + 1) for agent k, df = 0        :207-210
+    the warm start is passed for t > 1 only (mpc mode: t >= 1)                    :232 vs 478
+    cost: - V(W (x_N - mu)) sigma_t + mu_t replaces - (s_N - s_0)                 mpc.py:367-369
+    x_N = [s_tv, v_tv, e_tv, s_N - s_tv, v_N - v_tv, e_ego - e_tv] with (s_tv, v_tv) the LAST state of the other agent's
+    forecast as shared but NOT filtered (raw_preds = preds4CAV, evaluate.py:229; mpc.py:330) and e the scenario encoding
+    (utils.py:141-169; tests/golden/scenario_encoding.json holds the reference's own answers)
 
 What stands in for IPOPT is the sampled shooting solve of np_oracle (same candidate families as the device), so this
 pins the LOOP semantics -- who sees which forecast when, what the fallback does, what is shared -- not IPOPT's optimum.
@@ -52,6 +61,22 @@ def kparams_of(route):
     return np.array([np.inf, np.inf, 0.0]) if k['straight'] else np.array([k['b0'], k['b1'], k['Kv']])
 
 
+_ENC = None
+
+
+def scenario_encoding(routes):
+    """utils.py:141-169 -- looked up in the fixture the reference's own function produced (make_golden.py)."""
+    global _ENC
+    if _ENC is None:
+        here = os.path.dirname(os.path.abspath(__file__))
+        with open(os.path.join(here, '..', 'tests', 'golden', 'scenario_encoding.json')) as f:
+            _ENC = json.load(f)['scenario_encoding']
+    e = _ENC[f'{routes[0]},{routes[1]}']
+    if e is None:
+        raise ValueError('Scenario not found')
+    return e
+
+
 def augment_prev_sol(x_sol_prev, u_sol_prev, kp, P):
     """utils.py:354-363: shift the previous solution by one step; extend the states by one model step with the last
     control (retried with a = 0 if that step ends above v = 5; v clipped to [-1, 5]) and the controls by repeating the
@@ -68,16 +93,21 @@ def augment_prev_sol(x_sol_prev, u_sol_prev, kp, P):
 
 
 def run_episode(x_init, routes, P, cinf, M_sim=30, cand_mode='lattice', C=256, refine_iters=0, warm_start=True,
-                u_init=(0.1, 0.0)):
+                u_init=None, eval_mode='mpc', net=None):
     """x_init[M,7] (planner state order), routes = (route of agent 0, route of agent 1).
+    eval_mode 'gt_mpc' needs net = dict(layers, Wn, mu_f, sigma_t, mu_t) (np_oracle.terminal_value).
     -> dict(x_data[7M, M_sim+1], u_data[2M, M_sim], infeasible[M], deadlock, events)."""
     M, N, dt = len(routes), P.N, P.dt
     assert M == 2
+    gt = eval_mode == 'gt_mpc'
     consts = route_constants()
     A, b = cinf
     kp = [kparams_of(r) for r in routes]
     cur = [np.array(x_init[i], dtype=np.float64) for i in range(M)]
-    prev_in = [np.array(u_init, dtype=np.float64) for _ in range(M)]             # evaluate.py:419
+    if u_init is None:
+        u_init = (0.0, 0.0) if gt else (0.1, 0.0)                                # evaluate.py:171 / 419
+    code = scenario_encoding(routes) if gt else None                             # mpc.py:336-337
+    prev_in = [np.array(u_init, dtype=np.float64) for _ in range(M)]
     x_data = np.zeros((7 * M, M_sim + 1))
     u_data = np.zeros((2 * M, M_sim))
     for i in range(M):
@@ -94,20 +124,27 @@ def run_episode(x_init, routes, P, cinf, M_sim=30, cand_mode='lattice', C=256, r
                 events['share'] += 1
                 if np.clip(plan[0][5, N] + plan[1][0, N - 1] * dt, -2.0, 20.0) > 5:        # utils.py:348 (inside forecast_for_ego)
                     events['share_retry'] += 1
-            obs, _ = O.forecast_for_ego(routes[j], consts[routes[j]], cur[i][:2], cur[i][6], cur[j], prev_in[j][0], N, dt,
-                                        None if plan is None else plan[0], None if plan is None else plan[1])
+            a_fc = prev_in[j][0]
+            if gt and t == 0:
+                a_fc = 0.0 + 0.09 * (j + 1)                                                # evaluate.py:207-210
+            obs, tv = O.forecast_for_ego(routes[j], consts[routes[j]], cur[i][:2], cur[i][6], cur[j], a_fc, N, dt,
+                                         None if plan is None else plan[0], None if plan is None else plan[1])
             flags = np.array([O.FLAG_ABS_HEADING if routes[i] in ABS_HEADING_ROUTES else 0], dtype=np.uint32)
             u_ws = None
-            if warm_start and cand_mode in ('ramp_hold', 'track') and i in prev_idx:       # evaluate.py:478-481
+            if warm_start and cand_mode in ('ramp_hold', 'track') and i in prev_idx and t > (1 if gt else 0):   # :478 / :232
                 xs_p, us_p = prev_sols[prev_idx.index(i)]
                 u_ws = augment_prev_sol(xs_p, us_p, kp[i], P)[1][None]
                 flags = flags | np.uint32(O.FLAG_WARM)
                 events['warm'] += 1
             args = (cur[i][None], prev_in[i][None], kp[i][None], flags, obs[None, None], A, b, P)
+            kw = {}
+            if gt:
+                kw = dict(net=net, tv_sv=np.array([tv], dtype=np.float64),
+                          enc=np.array([[code[i], code[j]]], dtype=np.float64))
             if cand_mode in ('ramp_hold', 'track'):
-                r = O.solve_batch_refined(*args, C=C, refine_iters=refine_iters, u_ws=u_ws, cand=cand_mode)[-1]
+                r = O.solve_batch_refined(*args, C=C, refine_iters=refine_iters, u_ws=u_ws, cand=cand_mode, **kw)[-1]
             else:
-                r = O.solve_batch(*args, C=C)
+                r = O.solve_batch(*args, C=C, **kw)
             if r['status'][0] == 0:                                                        # evaluate.py:484-510
                 xs, us = r['x'][0], r['u'][0]
                 sols.append((xs, us))

@@ -522,6 +522,98 @@ def test_closed_loop_matches_oracle_loop(cand_mode):
     assert (ev['warm'] > 0) == (cand_mode != 'lattice')
 
 
+@pytest.mark.parametrize('cand_mode,N', [('track', 20), ('lattice', 20), ('track', 40)])
+def test_closed_loop_gt_mpc_matches_oracle_loop(cand_mode, N):
+    """eval_mode='gt_mpc' (evaluate.py:202-330) against oracle/closed_loop.py's gt mode, at 1e-9: (0, 0) initial inputs
+    (:171), the first step's forecast with a = 0.09 (k + 1) (:207-210), warm start for t > 1 only (:232), the terminal
+    value of (s_tv, v_tv) taken from the shared but UNFILTERED forecast (mpc.py:330), the scenario encodings, and a
+    synthetic non-identity whitening / de-normalisation (the reference's statistics are not shipped).  Also the loop at
+    the horizon the reference ships (N = 40, mpc.yaml:6)."""
+    import closed_loop as CL
+    from igtmpc import routes as R, shipped_value_net
+    from igtmpc.cinf import cinf_halfplanes
+    from igtmpc.evaluate import initial_states, run_closed_loop
+    rng = np.random.default_rng(5)
+    net = dict(shipped_value_net(1), Wn=np.eye(6) + 0.05 * rng.normal(size=(6, 6)),
+               mu_f=np.array([20.0, 2.5, 0.0, 0.0, 0.0, 0.0]) + 0.1 * rng.normal(size=6), sigma_t=3.0, mu_t=-1.5)
+    pairs = [R.SCENARIO_ROUTES[0][0], R.SCENARIO_ROUTES[0][3], R.SCENARIO_ROUTES[0][1]]      # scenario 1: ('13','23'), ('12','42'), ('24','34')
+    x, _ = initial_states(np.random.default_rng(2026), pairs)
+    x[0, :, 5], x[1, :, 5] = 2.0, 2.5
+    x[2, 0, 3], x[2, 0, 5] = 0.25, 0.3                            # |ey_0| > 0.2: agent 0 falls back from the first step on
+    x[2, 1, 5] = 2.0
+    M_sim = 24 if N == 20 else 12
+    P = O.Params(N=N)
+    got = run_closed_loop(N=N, T_sim=M_sim * 0.1, dtype='f64', cand_mode=cand_mode, init=(x, pairs), eval_mode='gt_mpc',
+                          value_net=net)
+    dev = run_closed_loop(N=N, T_sim=M_sim * 0.1, dtype='f64', cand_mode=cand_mode, init=(x, pairs), eval_mode='gt_mpc',
+                          value_net=net, device_resident=True)
+    assert np.array_equal(got['x_data'], dev['x_data']) and np.array_equal(got['u_data'], dev['u_data'])
+    ev = dict(fallback=0, stop=0, share=0, share_retry=0, warm=0)
+    for e in range(len(pairs)):
+        ref = CL.run_episode(x[e], pairs[e], P, cinf_halfplanes(), M_sim=M_sim, cand_mode=cand_mode, eval_mode='gt_mpc',
+                             net=net)
+        for k in ev:
+            ev[k] += ref['events'][k]
+        assert rel_err(got['x_data'][e], ref['x_data']).max() < 1e-9, (e, pairs[e])
+        assert rel_err(got['u_data'][e], ref['u_data']).max() < 1e-9, (e, pairs[e])
+        assert np.array_equal(got['infeasible_ratio'][e] * M_sim, ref['infeasible']), (e, pairs[e])
+        assert bool(got['deadlock'][e]) == ref['deadlock']
+    assert ev['fallback'] > 0 and ev['share'] > 0, ev
+    assert (ev['warm'] > 0) == (cand_mode == 'track')
+    if cand_mode == 'track':      # agents that solved steps 0 and 1 got no warm start at t = 1: at most M_sim - 2 each
+        assert ev['warm'] <= 2 * len(pairs) * (M_sim - 2)
+
+
+def test_gt_mpc_warm_start_begins_at_t2_not_t1():
+    """evaluate.py:232 vs :478, observed from outside: with tracking candidates the t = 1 solve of the gt_mpc loop is the
+    solve of a loop run WITHOUT warm starts, while the mpc loop's t = 1 solve differs from its cold twin (in at least one
+    of the episodes) -- and from t = 2 on the gt_mpc loop uses its warm start too."""
+    from igtmpc.evaluate import run_closed_loop
+    kw = dict(sc=1, num_samples=6, N=20, T_sim=0.6, dtype='f64', cand_mode='track')
+    g_w = run_closed_loop(eval_mode='gt_mpc', warm_start=True, **kw)
+    g_c = run_closed_loop(eval_mode='gt_mpc', warm_start=False, **kw)
+    assert np.array_equal(g_w['u_data'][:, :, :2], g_c['u_data'][:, :, :2])
+    assert not np.array_equal(g_w['u_data'][:, :, 2:], g_c['u_data'][:, :, 2:])
+    m_w = run_closed_loop(eval_mode='mpc', warm_start=True, **kw)
+    m_c = run_closed_loop(eval_mode='mpc', warm_start=False, **kw)
+    assert np.array_equal(m_w['u_data'][:, :, :1], m_c['u_data'][:, :, :1])
+    assert not np.array_equal(m_w['u_data'][:, :, 1], m_c['u_data'][:, :, 1])
+
+
+def test_mpc_planner_takes_nn_config_dir_like_the_reference(tmp_path):
+    """evaluate.py:191: MPC_Planner(..., use_NN_cost2go=True, nn_config_dir=get_scenario_config(sc)) -- the reference's
+    own gt_mpc call shape -- works unchanged: the YAML names the scenario's checkpoint, the shipped weights are taken,
+    identity statistics are announced by a warning, and the planner answers what a planner given the same network
+    explicitly answers."""
+    import igtmpc
+    cfg = tmp_path / 'game_theoretic_NN' / 'configs'
+    cfg.mkdir(parents=True)
+    (cfg / 'sc1_config.yaml').write_text('model_path: /game_theoretic_NN/models/V_GT_sc1.pt\ninclude_route: False\n'
+                                         'hidden_size: 128\nnum_layers: 2\ninput_size: 6\n')
+    routes, agents, refs = _scene()
+    N = 20
+    pred = igtmpc.ConstantAccelerationModel(N=N, dt=0.1)
+    preds = pred.predict(agents, [igtmpc.VehicleAction({'a': 0.0, 'df': 0.0}) for _ in routes], routes, refs)
+    kw = dict(N=N, dt=0.1, ca_radius=2.8, agents=agents, routes=routes, ref=refs, goals=None, road_dim=(11.4, 50),
+              ds_right=8.6, index=0, num_rk4_steps=4, use_NN_cost2go=True, ca_type='circle', weights=[1, 1, 1])
+    with pytest.warns(UserWarning, match='normalisation statistics'):
+        a = igtmpc.MPC_Planner(nn_config_dir=str(cfg / 'sc1_config.yaml'), **kw)
+    b = igtmpc.MPC_Planner(value_net=igtmpc.shipped_value_net(1), **kw)
+    assert a._solver is b._solver                                   # same content -> same shared handle
+    out = []
+    for pl in (a, b):
+        pl.update_initial_condition(agents[0], igtmpc.VehicleAction({'a': 0.0, 'df': 0.0}))
+        pl.update_predictions(preds, raw_preds=preds)
+        out.append(pl.solve())
+    assert out[0][2] and out[1][2]
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    with pytest.warns(UserWarning):                                  # no file there: the path's own name says which scenario
+        c = igtmpc.MPC_Planner(nn_config_dir='/somewhere/else/game_theoretic_NN/configs/sc1_config.yaml', **kw)
+    assert c._solver is a._solver
+    with pytest.raises(ValueError):
+        igtmpc.MPC_Planner(nn_config_dir=str(tmp_path / 'nothing.yaml'), **kw)
+
+
 def test_c_abi_allgather_controls_single_rank():
     """igt_comm_* / igt_allgather_controls_* through ctypes on one GPU: without a communicator the gather is the strided
     copy u*[:, :, 0]; with a world-of-one RCCL communicator (same ncclAllGather call every rank of an N-GPU job makes)
@@ -551,7 +643,16 @@ def test_c_abi_allgather_controls_single_rank():
         L.check(s.lib.igt_allgather_controls_f64(s._h, 4096, out['u'].data_ptr(), got2.data_ptr(), st))
         torch.cuda.synchronize()
         assert torch.equal(got2.nan_to_num(), want.nan_to_num())
+        # with a communicator an empty shard, or a shard size other than the first call's, is refused -- a rank that
+        # skipped the collective would leave its peers waiting inside ncclAllGather
+        for B_bad in (0, 2048):
+            with pytest.raises(igtmpc.IgtError):
+                L.check(s.lib.igt_allgather_controls_f64(s._h, B_bad, out['u'].data_ptr(), got2.data_ptr(), st))
         L.check(s.lib.igt_comm_destroy(s._h))
+        L.check(s.lib.igt_allgather_controls_f64(s._h, 0, out['u'].data_ptr(), got2.data_ptr(), st))     # no communicator: a no-op
+        L.check(s.lib.igt_allgather_controls_f64(s._h, 2048, out['u'].data_ptr(), got2.data_ptr(), st))
+        torch.cuda.synchronize()
+        assert torch.equal(got2[:2048].nan_to_num(), want[:2048].nan_to_num())
 
 
 def test_frenet_step_f32_outside_the_speed_box():

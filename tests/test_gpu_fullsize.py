@@ -122,7 +122,8 @@ def test_config3_shard_32768(igt, dtype, tol, eps):
     _run(igt, 32768, 3 * 32768, dtype, tol, eps)
 
 
-@pytest.mark.parametrize('dtype,tol,eps,sc', [('f64', 1e-9, 1e-9, 1), ('f32', REL_TOL, F32_EPS, 1), ('f32', REL_TOL, F32_EPS, 3)])
+@pytest.mark.parametrize('dtype,tol,eps,sc', [('f64', 1e-9, 1e-9, 1), ('f64', 1e-9, 1e-9, 3), ('f32', REL_TOL, F32_EPS, 1),
+                                              ('f32', REL_TOL, F32_EPS, 3)])
 def test_config4_gt_mpc_65536(igt, golden_dir, dtype, tol, eps, sc):
     """BASELINE configs[4]: gt_mpc, terminal value network (shipped V_GT_sc1: 2 hidden layers, V_GT_sc3: 3) evaluated
     on the GPU inside the cost, batch = 65 536 (per GPU; the 8-GPU run itself is the driver's)."""

@@ -292,3 +292,122 @@ def test_design_cites_profiles_that_exist_and_belong_together():
     if bm.source_hash() != m.group(1):      # kernels changed since the profiles were collected: bench.py prints null PMC fields
         warnings.warn(f'profiles/ were collected at {m.group(1)}, the kernel sources are now {bm.source_hash()}: '
                       f're-run tools/r02_collect.sh + tools/r02_publish.py')
+
+
+def test_value_net_from_config_reads_the_reference_yaml_shape(tmp_path):
+    """mpc.py:72-74, 108-124 / evaluate.py:191: nn_config_dir is a sc{n}_config.yaml naming the checkpoint; the shipped
+    weights of that scenario are returned, identity statistics are announced, a wrong architecture is refused."""
+    import warnings
+    from igtmpc.planner import value_net_from_config
+    from igtmpc.value_nets import shipped_value_net
+    d = tmp_path / 'configs'
+    d.mkdir()
+    for sc, nl in ((1, 2), (3, 3)):
+        (d / f'sc{sc}_config.yaml').write_text(f'data_path: /game_theoretic_NN/dataset/processed_sc{sc}.pkl\n'
+                                               f'model_path: /game_theoretic_NN/models/V_GT_sc{sc}.pt\nN: 10\n'
+                                               f'include_route: False\nhidden_size: 128\nnum_layers: {nl}\ninput_size: 6\n')
+        with pytest.warns(UserWarning, match='identity statistics'):
+            net, include_route = value_net_from_config(str(d / f'sc{sc}_config.yaml'))
+        want = shipped_value_net(sc)['layers']
+        assert not include_route and len(net['layers']) == nl + 1
+        assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(net['layers'], want))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        net, _ = value_net_from_config('/not/there/game_theoretic_NN/configs/sc6_config.yaml')      # by name
+        assert len(net['layers']) == 4
+        (d / 'sc2_config.yaml').write_text('model_path: /game_theoretic_NN/models/V_GT_sc2.pt\nnum_layers: 3\nhidden_size: 128\n')
+        with pytest.raises(ValueError, match='num_layers'):
+            value_net_from_config(str(d / 'sc2_config.yaml'))
+        with pytest.raises(ValueError):
+            value_net_from_config(str(tmp_path / 'whatever.yaml'))
+
+
+def test_oracle_gt_loop_rules():
+    """oracle/closed_loop.py gt mode (evaluate.py:171, 207-210, 232): (0, 0) initial inputs, warm starts counted from t = 2,
+    and a first-step forecast that differs from the mpc branch's."""
+    import closed_loop as CL
+    import np_oracle as O
+    from igtmpc import routes as R
+    from igtmpc.cinf import cinf_halfplanes
+    from igtmpc.evaluate import initial_states
+    from igtmpc.value_nets import shipped_value_net
+    pair = R.SCENARIO_ROUTES[0][0]
+    x, _ = initial_states(np.random.default_rng(2026), [pair])
+    x[0, :, 5] = 2.0
+    net = dict(shipped_value_net(1), Wn=np.eye(6), mu_f=np.zeros(6), sigma_t=1.0, mu_t=0.0)
+    P = O.Params(N=20)
+    g = CL.run_episode(x[0], pair, P, cinf_halfplanes(), M_sim=4, cand_mode='track', eval_mode='gt_mpc', net=net)
+    m = CL.run_episode(x[0], pair, P, cinf_halfplanes(), M_sim=4, cand_mode='track')
+    assert g['events']['warm'] == 2 * 2 and m['events']['warm'] == 2 * 3          # t = 2, 3 vs t = 1, 2, 3
+    assert np.abs(g['u_data'][0::2, 0]).max() <= 0.09 + 1e-12                      # |a_0 - 0| <= dt * jerk from u_prev = (0, 0)
+    assert not np.array_equal(g['u_data'], m['u_data'])
+    assert CL.scenario_encoding(pair) in ([1, -1], [-1, 1])
+
+
+@pytest.mark.parametrize('case', ['lattice', 'table_all', 'no_obs_no_cinf', 'two_obs', 'empty'])
+def test_c_oracle_is_clean_under_asan_and_ubsan(tmp_path, case):
+    """SURVEY section 5 (sanitizers): oracle/igt_oracle.c built with -fsanitize=address,undefined (host; the pool has no
+    GPU sanitizer) runs exactly-sized heap inputs without a report and returns, bit for bit, what the ordinary -O3 build
+    returns -- lattice and table candidates, 0 / 1 / 2 obstacles, with and without C_inf, an empty batch."""
+    import subprocess
+    import c_oracle as CO
+    import np_oracle as O
+    from igtmpc.cinf import cinf_halfplanes
+    from igtmpc.scenarios import make_batch
+    here = os.path.join(ROOT, 'oracle')
+    subprocess.run(['make', '-C', here, 'asan'], check=True, capture_output=True)
+    B, N, C = (0 if case == 'empty' else 12), 20, 64
+    n_obs = {'no_obs_no_cinf': 0, 'two_obs': 2}.get(case, 1)
+    A, b = (np.zeros((0, 2)), np.zeros(0)) if case == 'no_obs_no_cinf' else cinf_halfplanes()
+    bt = make_batch(max(B, 1), N=N, dtype=np.float64)
+    x0, up, kp, fl = bt['x0'][:B], bt['u_prev'][:B], bt['kparams'][:B], bt['flags'][:B]
+    obs = np.concatenate([bt['obs_xy'][:B]] * 2, axis=1)[:, :n_obs] if n_obs else np.zeros((B, 0, 2, N + 1))
+    table = case == 'table_all'
+    U = None
+    if table:
+        U = O.candidates_lattice(bt['u_prev'][:1], O.Params(N=N), C)[0] + 0.001
+    hdr = np.array([B, N, 4, C, n_obs, len(b), int(table), int(table)], dtype=np.int32)
+    with open(tmp_path / 'in.bin', 'wb') as f:
+        f.write(hdr.tobytes())
+        for a in (x0, up, kp, obs, A, b) + ((U,) if table else ()):
+            f.write(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+        f.write(np.ascontiguousarray(fl, dtype=np.uint32).tobytes())
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0', UBSAN_OPTIONS='print_stacktrace=1')
+    r = subprocess.run([os.path.join(here, 'asan_driver'), str(tmp_path / 'in.bin'), str(tmp_path / 'out.bin')],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and 'runtime error' not in r.stderr and 'AddressSanitizer' not in r.stderr, r.stderr[-2000:]
+    raw = open(tmp_path / 'out.bin', 'rb').read()
+    P = O.Params(N=N)
+    cinf = (None, None) if len(b) == 0 else (A, b)
+    if table:
+        ref = CO.rollout_all(x0, up, kp, fl, obs, *cinf, P, C=C, U=U, nthreads=2)
+        want = b''.join(ref[k].tobytes() for k in ('X', 'U', 'cost', 'viol'))
+    else:
+        ref = CO.solve_batch(x0, up, kp, fl, obs, *cinf, P, C=C, nthreads=2) if B else None
+        want = b''.join(ref[k].tobytes() for k in ('x', 'u', 'cost', 'argmin', 'status')) if B else b''
+    assert raw == want
+
+
+def test_c_abi_argument_validation_without_a_gpu():
+    """The C ABI's argument checks that come before any device call (no GPU here): null pointers and invalid
+    parameters return an IGT_E_* code with a message -- no crash, no exception across the boundary."""
+    from igtmpc import _lib as L
+    lib = L.load()
+    assert lib.igt_params_default(None) != 0 and lib.igt_last_error()
+    p = L.igt_params()
+    assert lib.igt_params_default(ct.byref(p)) == 0
+    h = ct.c_void_p()
+    for field, bad in (('N', 0), ('C', 100), ('n_rk4', 0), ('n_obs', -1), ('dt', -0.1), ('cand_mode', 99)):
+        q = L.igt_params()
+        lib.igt_params_default(ct.byref(q))
+        setattr(q, field, bad)
+        assert lib.igt_create(ct.byref(q), 0, ct.byref(h)) != 0, field
+        assert lib.igt_last_error()
+    assert lib.igt_create(None, 0, ct.byref(h)) != 0
+    assert lib.igt_create(ct.byref(p), 0, None) != 0
+    for name in ('igt_destroy', 'igt_comm_destroy'):
+        getattr(lib, name)(None)                                     # tolerated or refused, never a crash
+    assert lib.igt_set_cinf(None, None, None, 0) != 0
+    assert lib.igt_comm_init(None, 1, 0, None) != 0
+    assert lib.igt_allgather_controls_f64(None, 4, None, None, None) != 0
+    assert lib.igt_set_profiling(None, 1) != 0
