@@ -10,15 +10,19 @@ scenarios per GPU (SURVEY.md section 8d generator), inputs already resident in H
   + for N > 1: RCCL all-gather of the first-step controls u*[:, :, 0].
 
 The headline (`value`, `dtype`) is the float64 entry igt_solve_batch_f64 -- the reference's own precision
-(kinematic_bicycle_model_frenet.py:70-127 and mpc.py are float64 end to end); the float32 entry
-(float stage derivatives, double state accumulators) is timed in the same run and reported beside it as
-`f32_path`.
+(kinematic_bicycle_model_frenet.py:70-127 and mpc.py are float64 end to end) -- on BASELINE configs[1]
+(B = 4096 per GPU, SURVEY 8d's lattice candidates).  The same JSON line carries, timed in the same run:
+  * `one_solve_in_flight`  -- the same workload with every step waiting for the previous one (what a closed MPC loop
+                              sees), with the kernel durations the `roofline` block refers to;
+  * `tracking_family`      -- the same batch through IGT_CAND_TRACK, the family MPC_Planner / igtmpc.evaluate use;
+  * `f32_path`             -- the float32 entry;
+  * `configs`              -- BASELINE configs[2] (B = 65 536) and configs[4] (gt_mpc, B = 65 536; lattice and tracking).
 
 Steps are pipelined (`--in-flight F`, default 4): step t is enqueued on handle / stream t mod F -- every handle owns
 its workspace and its output buffers, the inputs are read-only -- so the emit pass (one roll-out of latency) and the
 drain tail of one step's search overlap the search pass of the next instead of being exposed.  All K steps complete
-inside the timed region; the one-solve-at-a-time figure (`--in-flight 1`) is measured in the same run and printed as
-`one_solve_in_flight`.
+inside the timed region.  Before the W warm-up steps an untimed settle phase (`--settle-ms`, default 150 ms of the same
+steps) lets the shader clock reach its working point: with it a 20-step and a 200-step call report the same rate.
 
 N > 1: one process per GPU, each solving its own contiguous shard (weak scaling, no data-path collective).
 The driver launches that as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`; a plain
@@ -39,19 +43,23 @@ sys.path.insert(0, os.path.join(ROOT, 'igt-mpc-int_amd'))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SIMDS = 256 * 4                # 256 CUs x 4 SIMDs
-VALU_ISSUE_CYCLES = 4          # a wave64 VALU instruction occupies its SIMD's 16 lanes for 4 cycles
-PEAK_CLOCK_GHZ = 2.4           # MI355X_MICROARCH.md: peak engine clock (the issue capacity the fraction is taken of)
+PEAK_CLOCK_GHZ = 2.4           # MI355X_MICROARCH.md: peak engine clock
 N_HORIZON, N_CAND = 20, 256
+PROFILE_ROUND = 'r03'          # profiles/<round>_pmc_*.json: the rocprofv3 --pmc passes of this command (tools/collect.sh)
 
 
-def default_batch(n_gpus):
-    """Scenarios per GPU: BASELINE configs[1] (4096) up to 4 GPUs; configs[3] (262 144 sharded 8 ways = 32 768) at 8."""
+def default_batch(n_gpus, gt=0):
+    """Scenarios per GPU: BASELINE configs[1] (4096) up to 4 GPUs; configs[3] (262 144 sharded 8 ways = 32 768) at 8;
+    configs[4] (gt_mpc) is quoted at 65 536 scenarios per GPU whatever the number of GPUs (weak scaling)."""
+    if gt:
+        return 65536
     return 32768 if n_gpus >= 8 else 4096
 
 
-def workload_name(B, n_gpus, gt):
+def workload_name(B, n_gpus, gt, cand='lattice'):
     if gt:
-        tag = 'BASELINE configs[4] (gt_mpc, batch=65536 per GPU)' if B == 65536 else 'custom gt_mpc batch'
+        tag = (f'BASELINE configs[4] (gt_mpc, batch=65536 per GPU{", x%d GPUs" % n_gpus if n_gpus > 1 else ""})'
+               if B == 65536 else 'custom gt_mpc batch')
     elif B == 4096:
         tag = 'BASELINE configs[1]' if n_gpus == 1 else f'BASELINE configs[1] per GPU x{n_gpus}'
     elif B == 65536 and n_gpus == 1:
@@ -60,8 +68,9 @@ def workload_name(B, n_gpus, gt):
         tag = 'BASELINE configs[3] (262144 scenarios sharded 8 ways)'
     else:
         tag = 'custom batch'
+    fam = {'lattice': f'{N_CAND} lattice candidates', 'track': f'{N_CAND} tracking candidates (IGT_CAND_TRACK)'}[cand]
     return (f'{tag}: batch={B} two-vehicle intersection scenarios per GPU (all 8 sc variants tiled), horizon N={N_HORIZON}, '
-            f'{N_CAND} lattice candidates, 4 RK4 sub-steps, Frenet bicycle model, C_inf terminal set')
+            f'{fam}, 4 RK4 sub-steps, Frenet bicycle model, C_inf terminal set')
 
 
 def source_hash():
@@ -101,8 +110,9 @@ def host_cores():
 
 
 def cpu_baseline(batch, N, C, budget_s=12.0):
-    """The oracle's C restatement (oracle/igt_oracle.c, kind "port") on this host's cores,
-    on a bounded sample of the SAME workload.  Checker code timed as a baseline only."""
+    """The oracle's C restatement (oracle/igt_oracle.c, -O3 without fast-math, kind "port") on this host's cores, on a
+    bounded sample of the SAME workload; the numpy oracle on a smaller slice beside it.
+    Checker code timed as a baseline only."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import c_oracle as CO
@@ -134,10 +144,17 @@ def cpu_baseline(batch, N, C, budget_s=12.0):
     CO.solve_batch(f('x0', sl), f('u_prev', sl), f('kparams', sl), batch['flags'][sl], f('obs_xy', sl), A, b, P, C=C,
                    nthreads=1)
     t1 = time.perf_counter() - t0
+    # the numpy oracle (vectorised over scenarios x candidates, one process)
+    sn = slice(0, min(48, B))
+    t0 = time.perf_counter()
+    O.solve_batch(f('x0', sn), f('u_prev', sn), f('kparams', sn), batch['flags'][sn], f('obs_xy', sn), A, b, P, C=C)
+    tn = time.perf_counter() - t0
     return {'value': done / t_all, 'unit': 'solves/s', 'cores': cores, 'kind': 'port',
-            'sample': f'first {done} scenarios of the same batch, float64 C restatement (oracle/igt_oracle.c), '
-                      f'OpenMP over scenarios; reference mpc.py (CasADi/IPOPT) cannot run on this image',
-            'single_thread_value': (sl.stop - sl.start) / t1}
+            'sample': f'first {done} scenarios of the same batch, float64 C restatement (oracle/igt_oracle.c, gcc -O3, no '
+                      f'fast-math), OpenMP over scenarios; reference mpc.py (CasADi/IPOPT) cannot run on this image',
+            'single_thread_value': (sl.stop - sl.start) / t1,
+            'numpy_oracle_value': (sn.stop - sn.start) / tn,
+            'numpy_oracle_sample': f'first {sn.stop - sn.start} scenarios, oracle/np_oracle.py, one process'}
 
 
 def spawn_ranks(args, argv):
@@ -165,9 +182,11 @@ def spawn_ranks(args, argv):
         return 2
 
 
-def rehearse_cpu(world, rank):
-    """CPU rehearsal of the launch path (tests only: `--rehearse-cpu`): the ranks meet over gloo, all-gather a token and
-    rank 0 reports how many ranks it saw.  No solve, no GPU."""
+def rehearse_cpu(args, world, rank):
+    """CPU rehearsal of the launch path (tests only: `--rehearse-cpu`): the ranks meet over gloo, all-gather a token,
+    take the MAX of a per-rank time like the timed region does, and rank 0 assembles the SAME JSON line the GPU run
+    prints -- from placeholder measurements (every rate is null) -- so that the multi-GPU line, the gt_mpc one included,
+    is exercised without a GPU.  No solve."""
     import torch
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -175,13 +194,159 @@ def rehearse_cpu(world, rank):
     tok = torch.tensor([rank], dtype=torch.int64)
     got = [torch.zeros_like(tok) for _ in range(world)]
     dist.all_gather(got, tok)
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
-        print(json.dumps({'rehearsal': True, 'ranks_seen': dist.get_world_size(), 'backend': dist.get_backend(),
-                          'tokens': [int(t.item()) for t in got],
-                          'spawned_by_bench': os.environ.get('IGT_BENCH_SPAWNED') == '1'}), flush=True)
+        B = args.batch if args.batch else default_batch(world, args.gt)
+        fake = lambda Bm: dict(dtype=args.dtype, B=Bm, elapsed=float(t.item()), steps=args.steps, value=None, ms_per_step=None,
+                               search_ms=None, emit_ms=None, rd=0, wr=0, feasible=None, in_flight=args.in_flight,
+                               lane_search_ms=None, lane_emit_ms=None)
+        same = fake(default_batch(1)) if (world > 1 and B != default_batch(1) and not args.batch and not args.gt) else None
+        line = assemble_line(args, fake(B), n_gpus=world, world=world, backend=dist.get_backend(), exchange=world > 1,
+                             same_work=same, n_layers=3 if args.gt else 0)
+        line.update({'rehearsal': True, 'ranks_seen': dist.get_world_size(), 'backend': dist.get_backend(),
+                     'tokens': [int(x.item()) for x in got], 'max_over_ranks_s': float(t.item()),
+                     'spawned_by_bench': os.environ.get('IGT_BENCH_SPAWNED') == '1'})
+        print(json.dumps(line), flush=True)
     dist.barrier()
     dist.destroy_process_group()
     return 0
+
+
+def pmc_profile(dtype, gt, B, cand='lattice'):
+    """The committed rocprofv3 --pmc summary of this workload, if it was collected at the kernel sources the library is
+    built from (otherwise None: a counter of another binary is not quoted)."""
+    name = f'{PROFILE_ROUND}_pmc_{dtype}{"_gt%d" % gt if gt else ""}{"_track" if cand == "track" else ""}_b{B}.json'
+    path = os.path.join(ROOT, 'profiles', name)
+    if not os.path.exists(path):
+        return None, None
+    try:
+        with open(path) as f:
+            tj = json.load(f)
+    except Exception:
+        return None, None
+    if tj.get('source_hash') != source_hash() or tj.get('batch') != B:
+        return None, None
+    return tj, (f'{os.path.relpath(path, ROOT)} (rocprofv3 --pmc passes of this command, one solve in flight, at source hash '
+                f'{tj.get("source_hash")}; not measured by this run)')
+
+
+def assemble_line(args, head, n_gpus, world, backend, exchange, other=None, serial=None, tracking=None, same_work=None,
+                  configs=None, cpu=None, n_layers=0):
+    """The one JSON line, from the measurements (a pure function: tests/test_host_logic.py builds the N = 8 gt_mpc line
+    from placeholders)."""
+    B = head['B']
+    other_dtype = 'f32' if args.dtype == 'f64' else 'f64'
+    # kernel durations of the roofline block: measured with ONE solve in flight (HIP events on the launch stream) --
+    # `serial` when the headline is pipelined, the headline itself when it is not
+    ref = serial if serial is not None else head
+    search_ms, emit_ms, rd = ref['search_ms'], ref['emit_ms'], head['rd']
+    bytes_per_launch = (rd + 12) * B          # search kernel: reads inputs, writes cost/argmin/status partials
+    ach = bytes_per_launch / (search_ms * 1e-3) / 1e9 if search_ms else None
+    tj, pmc_src = pmc_profile(args.dtype, args.gt, B)
+    d = (tj or {}).get('derived', {})
+    traffic = (tj or {}).get('search_kernel_hbm_bytes_per_launch')
+    valu = {'bound': 'valu_busy', 'unit': 'fraction of SIMD cycles the vector ALU is busy',
+            'definition': 'SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles), counters and shader clock '
+                          '(GRBM_GUI_ACTIVE) from the same rocprofv3 --pmc passes of this command',
+            'regime': 'one solve in flight (the counter passes serialise the kernels)',
+            'achieved': d.get('simd_valu_busy_fraction'), 'peak': 1.0, 'frac': d.get('simd_valu_busy_fraction'),
+            'valu_instructions_per_launch': d.get('valu_instructions_per_launch'),
+            'valu_instructions_per_unit': d.get('valu_instructions_per_unit'),
+            'busy_cycles_per_valu_instruction': d.get('busy_cycles_per_valu_instruction'),
+            'mean_waves_resident_per_simd': d.get('mean_waves_resident_per_simd'),
+            'shader_clock_ghz_measured': d.get('shader_clock_GHz_during_search'),
+            'kernel_ms_under_profiler': d.get('search_kernel_ms'),
+            'issue_fraction_at_4_cycles_per_instruction': d.get('valu_issue_fraction_4_cycles_per_instruction'),
+            'microbenchmark': d.get('microbenchmark_cycles_per_instruction'),
+            'source': pmc_src}
+    if d.get('valu_instructions_per_launch') and head['ms_per_step']:
+        # the same instruction count against the whole (pipelined) step `value` is made of, at the measured busy cycles
+        # per instruction: how much of the step the vector ALUs would be busy if only that work existed
+        clk = d.get('shader_clock_GHz_during_search') or PEAK_CLOCK_GHZ
+        cpi = d.get('busy_cycles_per_valu_instruction') or 4.0
+        valu['busy_fraction_of_whole_step'] = (d['valu_instructions_per_launch'] * cpi /
+                                               (SIMDS * head['ms_per_step'] * 1e-3 * clk * 1e9))
+    arith = {'f64': 'float64 throughout (stage derivatives, state, cost, verdicts)',
+             'f32': 'float32 stage derivatives + float64 state accumulators, cost and verdicts'}
+    F = head['in_flight']
+    line = {
+        'metric': 'mpc_solves_per_sec', 'value': head['value'], 'unit': 'solves/s', 'n_gpus': n_gpus,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': head['ms_per_step'],
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': workload_name(B, n_gpus, args.gt, args.cand),
+                   'per_gpu_batch': B, 'global_batch': B * n_gpus,
+                   'entry_point': f'igt_solve_batch_{args.dtype}',
+                   'arithmetic': arith[args.dtype],
+                   'parallelism': (f'scenario shards x{n_gpus}, one process per GPU, all-gather of u*[:, :, 0] on its own '
+                                   f'stream under the next step') if exchange else 'single GPU',
+                   'ranks_seen': world if exchange else 1, 'backend': backend,
+                   'solves_in_flight': F,
+                   'pipelining': (f'step t runs on handle / stream t mod {F} (own workspace and output buffers each); '
+                                  f'all {args.steps} steps complete inside the timed region') if F > 1 else 'none',
+                   'settle_ms': args.settle_ms,
+                   'cost': (f'gt_mpc value net V_GT_sc{args.gt} ({n_layers - 1} hidden layers, igtmpc.shipped_value_net, identity '
+                            f'normalisation)') if args.gt else 'mpc progress cost',
+                   'feasible_fraction': head['feasible']},
+        'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': ach / HBM_PEAK_GBS if ach else None, 'traffic': traffic, 'traffic_source': pmc_src,
+                     'kernel': f'search kernel of igt_solve_batch_{args.dtype} (+ value kernels in gt mode)',
+                     'kernel_ms': search_ms, 'algorithmic_bytes_per_solve': rd + 12,
+                     'regime': 'one solve in flight: kernel_ms is the search kernel alone on the GPU (HIP events on its '
+                               'launch stream), the figure `one_solve_in_flight.ms_per_step` is made of; the headline '
+                               '`value` overlaps %d solves, see `pipelined`' % F if F > 1 else 'one solve in flight',
+                     'note': 'BASELINE.json names the HBM roofline; the path is vector-ALU-bound (arithmetic intensity ~1e4 '
+                             'flop/B) -- the bound that applies is `valu_roofline`'},
+        'valu_roofline': valu,
+        'kernels_ms': {'search': search_ms, 'emit': emit_ms, 'regime': 'one solve in flight'},
+        'whole_solve_bytes': rd + head['wr'],
+        'precision': {'f64': 'igt_solve_batch_f64: <= 1e-9 of the float64 oracle on every trajectory (curvature '
+                             'break-point straddlers included)',
+                      'f32': 'igt_solve_batch_f32: <= 1e-5*max(1,|ref|) except trajectories whose curvature switch is '
+                             'decided inside float32 noise (share measured in tests/test_gpu_parity.py)'},
+    }
+    if F > 1:
+        line['pipelined'] = {
+            'solves_in_flight': F, 'ms_per_step': head['ms_per_step'],
+            'kernels_ms_while_overlapped': {'search': head.get('lane_search_ms'), 'emit': head.get('lane_emit_ms')},
+            'note': 'durations of one lane\'s kernels (HIP events on the lane\'s stream) while the other lanes\' kernels share the '
+                    'GPU: each kernel takes longer than alone, the step rate is higher because tails and emit passes overlap'}
+    if tracking is not None:
+        tt, tsrc = pmc_profile(args.dtype, args.gt, B, 'track')
+        line['tracking_family'] = {
+            'value': tracking['value'], 'unit': 'solves/s', 'ms_per_step': tracking['ms_per_step'], 'dtype': args.dtype,
+            'solves_in_flight': tracking['in_flight'],
+            'kernels_ms': {'search': tracking['search_ms'], 'emit': tracking['emit_ms'], 'regime': 'one solve in flight'},
+            'feasible_fraction': tracking['feasible'],
+            'valu_busy_fraction': ((tt or {}).get('derived', {}) or {}).get('simd_valu_busy_fraction'),
+            'valu_instructions_per_unit': ((tt or {}).get('derived', {}) or {}).get('valu_instructions_per_unit'),
+            'pmc_source': tsrc,
+            'note': 'same batch, entry point and timing with cand_mode = IGT_CAND_TRACK (256 candidates, one pass): '
+                    'the default family of MPC_Planner and igtmpc.evaluate'}
+    if other is not None:
+        line[f'{other_dtype}_path'] = {
+            'value': other['value'], 'unit': 'solves/s', 'ms_per_step': other['ms_per_step'], 'dtype': other_dtype,
+            'entry_point': f'igt_solve_batch_{other_dtype}', 'arithmetic': arith[other_dtype],
+            'kernels_ms': {'search': other['search_ms'], 'emit': other['emit_ms'], 'regime': 'one solve in flight'},
+            'steps': args.steps, 'warmup': args.warmup, 'feasible_fraction': other['feasible'],
+            'note': 'same workload, same run, timed exactly like the headline'}
+    if serial is not None:
+        line['one_solve_in_flight'] = {
+            'value': serial['value'], 'ms_per_step': serial['ms_per_step'], 'dtype': args.dtype,
+            'kernels_ms': {'search': serial['search_ms'], 'emit': serial['emit_ms']},
+            'note': 'same workload and entry point with --in-flight 1: step t+1 is enqueued behind step t on one stream, '
+                    'so every emit pass and every search drain tail is exposed -- what a closed MPC loop, where step t+1 '
+                    'needs step t, gets'}
+    if same_work is not None:
+        line['same_per_gpu_work_as_n1'] = {
+            'per_gpu_batch': same_work['B'], 'value': same_work['value'], 'ms_per_step': same_work['ms_per_step'],
+            'note': 'BASELINE configs[1] batch per GPU, for a weak-scaling comparison against the N=1 line'}
+    if configs:
+        line['configs'] = configs
+    if cpu is not None:
+        line['cpu_baseline'] = cpu
+    return line
 
 
 def main():
@@ -190,16 +355,21 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=None,
-                    help='scenarios per GPU per step (default: 4096 = BASELINE configs[1]; 32768 = configs[3] at --gpus 8)')
+                    help='scenarios per GPU per step (default: 4096 = BASELINE configs[1]; 32768 = configs[3] at --gpus 8; '
+                         '65536 = configs[4] with --gt)')
     ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'],
                     help="entry point behind the headline `value` (default f64: the reference's precision)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-secondary', action='store_true', help='skip the other-precision block')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the other-precision / serial / tracking blocks')
+    ap.add_argument('--no-configs', action='store_true', help='skip the configs[2] / configs[4] sub-records of the default run')
     ap.add_argument('--gt', type=int, default=0, metavar='SC',
-                    help='gt_mpc cost with the shipped value net of scenario SC (1 or 3; BASELINE configs[4]); 0 = mpc cost')
+                    help='gt_mpc cost with the shipped value net of scenario SC (1..8; BASELINE configs[4]); 0 = mpc cost')
+    ap.add_argument('--cand', default='lattice', choices=['lattice', 'track'], help='candidate family of the headline')
     ap.add_argument('--in-flight', type=int, default=4, choices=[1, 2, 3, 4, 5, 6, 8],
                     help='solves in flight: step t runs on handle/stream t mod F (each handle owns its workspace and '
                          'output buffers), so the emit pass and the drain tail of one step overlap the search pass of the next')
+    ap.add_argument('--settle-ms', type=float, default=150.0,
+                    help='untimed steps of the same work before the warm-up, until this much wall time has passed')
     ap.add_argument('--rehearse-cpu', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus < 1:
@@ -217,7 +387,7 @@ def main():
             print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}', file=sys.stderr)
             sys.exit(2)
     if args.rehearse_cpu:
-        sys.exit(rehearse_cpu(world, rank))
+        sys.exit(rehearse_cpu(args, world, rank))
 
     import numpy as np
     import torch
@@ -237,35 +407,35 @@ def main():
     dev = local_rank if world > 1 else 0
     torch.cuda.set_device(dev)
 
-    from igtmpc import BatchSolver
+    from igtmpc import BatchSolver, shipped_value_net
     from igtmpc.cinf import cinf_halfplanes
     from igtmpc.scenarios import make_batch
 
     N, C = N_HORIZON, N_CAND
-    B = args.batch if args.batch else default_batch(n_gpus)
-    layers = []
-    if args.gt:
-        g = np.load(os.path.join(ROOT, 'tests', 'golden', 'value_net_golden.npz'))
-        i = 0
-        while f'sc{args.gt}_W{i}' in g:
-            layers.append((g[f'sc{args.gt}_W{i}'], g[f'sc{args.gt}_b{i}']))
-            i += 1
+    B = args.batch if args.batch else default_batch(n_gpus, args.gt)
+    batches = {}
 
-    def measure(dtype, Bm, steps, warmup, in_flight=None, cand_mode='lattice'):
-        """W untimed + K timed steps of the `dtype` entry point at Bm scenarios per GPU, then per-kernel HIP events."""
+    def measure(dtype, Bm, steps, warmup, in_flight=None, cand_mode='lattice', gt=None, settle_ms=None):
+        """settle + W untimed + K timed steps of the `dtype` entry point at Bm scenarios per GPU, then per-kernel HIP
+        events (one solve at a time, and -- pipelined runs -- with the lanes overlapping)."""
+        gt = args.gt if gt is None else gt
         npdt = np.float64 if dtype == 'f64' else np.float32
         td = torch.float64 if dtype == 'f64' else torch.float32
-        batch = make_batch(Bm, N=N, dtype=npdt, offset=rank * Bm)
-        keys = ['x0', 'u_prev', 'kparams', 'flags', 'obs_xy'] + (['tv_sv', 'enc'] if args.gt else [])
+        if (Bm, dtype) not in batches:
+            batches.clear()                                  # one batch resident at a time (65 536 x f64 is ~50 MB on the host)
+            batches[(Bm, dtype)] = make_batch(Bm, N=N, dtype=npdt, offset=rank * Bm)
+        batch = batches[(Bm, dtype)]
+        layers = shipped_value_net(gt)['layers'] if gt else []      # the weights the package ships (identity whitening:
+        keys = ['x0', 'u_prev', 'kparams', 'flags', 'obs_xy'] + (['tv_sv', 'enc'] if gt else [])   # the statistics are not shipped)
         dargs = [torch.from_numpy(batch[k].view(np.int32) if batch[k].dtype == np.uint32 else batch[k]).cuda(dev) for k in keys]
         F = in_flight or args.in_flight
         solvers, outs, lanes = [], [], []
         for _ in range(F):
-            sv = BatchSolver(N=N, C=C, n_obs=1, device=dev, dtype=dtype, cost_mode='value_net' if args.gt else 'progress',
+            sv = BatchSolver(N=N, C=C, n_obs=1, device=dev, dtype=dtype, cost_mode='value_net' if gt else 'progress',
                              cand_mode=cand_mode)
             sv.set_cinf(*cinf_halfplanes(dt=sv.params.dt, jerk=sv.params.jerk_limit))
-            if args.gt:
-                sv.set_value_net(layers)      # identity whitening: the reference's statistics are not shipped
+            if gt:
+                sv.set_value_net(layers)
             solvers.append(sv)
             outs.append(sv.solve(*dargs))
             lanes.append(torch.cuda.Stream(dev) if F > 1 else None)
@@ -312,6 +482,21 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize(dev)
 
+        # settle: the same steps, untimed, until the clocks have reached their working point (every rank runs the same
+        # number: the count is agreed through the fence below, not by each rank's own clock -- an all-gather per step)
+        settle = args.settle_ms if settle_ms is None else settle_ms
+        n_settle = 0
+        if settle > 0:
+            t0 = time.perf_counter()
+            step(); torch.cuda.synchronize(dev)
+            per = max(time.perf_counter() - t0, 1e-5)
+            n_settle = int(min(2000, max(F, settle * 1e-3 / per)))
+            if exchange:
+                ns = torch.tensor([n_settle], dtype=torch.int64, device=f'cuda:{dev}')
+                dist.all_reduce(ns, op=dist.ReduceOp.MAX)
+                n_settle = int(ns.item())
+            for _ in range(n_settle):
+                step()
         for _ in range(warmup):
             step()
         fence()
@@ -325,10 +510,29 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
 
-        # per-kernel durations: HIP events recorded by the library on the launch stream, same workload
+        # per-kernel durations: HIP events recorded by the library on the launch stream, same workload.
+        # (1) pipelined runs: every lane profiles its own kernels while the other lanes' kernels overlap them
+        lane_s, lane_e = None, None
+        if F > 1:
+            for sv in solvers:
+                sv.set_profiling(True)
+            ls, le = [], []
+            n_prof = max(4 * F, min(steps, 48))
+            for t_ in range(n_prof):
+                q = t_ % F
+                if t_ >= F:
+                    a, e = solvers[q].kernel_ms()
+                    ls.append(a); le.append(e)
+                with torch.cuda.stream(lanes[q]):
+                    solvers[q].solve(*dargs, out=outs[q])
+            torch.cuda.synchronize(dev)
+            for sv in solvers:
+                sv.set_profiling(False)
+            lane_s, lane_e = float(np.mean(ls)), float(np.mean(le))
+        # (2) one solve at a time
         solver.set_profiling(True)
         ks, ke = [], []
-        for _ in range(min(steps, 50)):
+        for _ in range(max(8, min(steps, 50))):
             solver.solve(*dargs, out=out)
             a, e = solver.kernel_ms()
             ks.append(a)
@@ -337,114 +541,54 @@ def main():
         rd, wr = solver.algorithmic_bytes_per_solve()
         res = dict(dtype=dtype, B=Bm, elapsed=elapsed, steps=steps, value=Bm * n_gpus * steps / elapsed,
                    ms_per_step=elapsed / steps * 1e3, search_ms=float(np.mean(ks)), emit_ms=float(np.mean(ke)),
+                   lane_search_ms=lane_s, lane_emit_ms=lane_e, in_flight=F, settle_steps=n_settle,
                    rd=rd, wr=wr, feasible=float((out['status'] == 0).float().mean().item()), batch=batch)
         for sv in solvers:
             sv.close()
+        del dargs, outs
+        torch.cuda.empty_cache()
         return res
 
-    head = measure(args.dtype, B, args.steps, args.warmup)
+    head = measure(args.dtype, B, args.steps, args.warmup, cand_mode=args.cand)
+    cpu = None
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and not args.gt:
+        cpu = cpu_baseline(head['batch'], N, C)       # before the other measurements replace the resident batch
     other_dtype = 'f32' if args.dtype == 'f64' else 'f64'
-    other = None if args.no_secondary else measure(other_dtype, B, args.steps, args.warmup)
+    # one solve at a time (every step waits for the previous one's emit pass), for comparison with the pipelined headline
+    serial = measure(args.dtype, B, args.steps, args.warmup, in_flight=1, cand_mode=args.cand) \
+        if args.in_flight > 1 and not args.no_secondary else None
+    # the candidate family the planner and the closed-loop driver use by default (state-feedback steering, DESIGN.md section 9):
+    # the headline stays on SURVEY 8d's lattice, this is the same batch through the family that gives the better answers
+    tracking = None if (args.no_secondary or args.cand == 'track') else \
+        measure(args.dtype, B, args.steps, args.warmup, cand_mode='track')
     # the driver computes scaling efficiency from the per-N values; at N = 8 the per-GPU batch is configs[3]'s 32 768,
     # not configs[1]'s 4096, so the same-per-GPU-work figure is measured beside it in the same run
     same_work = None
-    if n_gpus > 1 and B != default_batch(1) and not args.batch:
-        same_work = measure(args.dtype, default_batch(1), args.steps, args.warmup)
-    # one solve at a time (every step waits for the previous one's emit pass), for comparison with the pipelined headline
-    serial = measure(args.dtype, B, args.steps, args.warmup, in_flight=1) if args.in_flight > 1 and not args.no_secondary else None
-    # the candidate family the planner and the closed-loop driver use by default (state-feedback steering, DESIGN.md section 9):
-    # the headline stays on SURVEY 8d's lattice, this is the same batch through the family that gives the better answers
-    tracking = None if args.no_secondary else measure(args.dtype, B, args.steps, args.warmup, cand_mode='track')
+    if n_gpus > 1 and B != default_batch(1) and not args.batch and not args.gt:
+        same_work = measure(args.dtype, default_batch(1), args.steps, args.warmup, cand_mode=args.cand)
+    other = None if args.no_secondary else measure(other_dtype, B, args.steps, args.warmup, cand_mode=args.cand)
+
+    # the other single-GPU BASELINE configurations, driver-timed in the same run (default invocation only):
+    # configs[2] = 65 536 scenarios; configs[4] = gt_mpc at 65 536 (V_GT_sc1; lattice and tracking candidates)
+    configs = []
+    if n_gpus == 1 and not args.no_configs and not args.batch and not args.gt and args.cand == 'lattice':
+        ks, kw = max(4, min(args.steps, 12)), max(2, min(args.warmup, 3))
+        for name, kwm in (('configs[2]', dict(Bm=65536, cand_mode='lattice', gt=0)),
+                          ('configs[4]', dict(Bm=65536, cand_mode='lattice', gt=1)),
+                          ('configs[4] through the tracking family', dict(Bm=65536, cand_mode='track', gt=1)),
+                          ('configs[4] with V_GT_sc3 (3 hidden layers)', dict(Bm=65536, cand_mode='lattice', gt=3))):
+            m = measure(args.dtype, kwm['Bm'], ks, kw, in_flight=1, cand_mode=kwm['cand_mode'], gt=kwm['gt'], settle_ms=60.0)
+            configs.append({'config': name, 'workload': workload_name(kwm['Bm'], 1, kwm['gt'], kwm['cand_mode']),
+                            'value': m['value'], 'unit': 'solves/s', 'ms_per_step': m['ms_per_step'], 'dtype': args.dtype,
+                            'steps': ks, 'warmup': kw, 'solves_in_flight': 1,
+                            'kernels_ms': {'search_incl_value_net': m['search_ms'], 'emit': m['emit_ms']},
+                            'feasible_fraction': m['feasible']})
 
     if rank == 0:
-        search_ms, emit_ms, rd = head['search_ms'], head['emit_ms'], head['rd']
-        bytes_per_launch = (rd + 12) * B          # search kernel: reads inputs, writes cost/argmin/status partials
-        ach = bytes_per_launch / (search_ms * 1e-3) / 1e9
-        # PMC figures (HBM bytes, VALU instruction count per launch) are properties of this workload + this binary; they
-        # come from the committed rocprofv3 --pmc passes of this same command and are quoted only when the profile was
-        # collected at the kernel sources this library was built from -- otherwise null.
-        traffic, valu_insts, pmc_src = None, None, None
-        tpath = os.path.join(ROOT, 'profiles', f'r02_pmc_{args.dtype}{"_gt%d" % args.gt if args.gt else ""}_b{B}.json')
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    tj = json.load(f)
-                if tj.get('source_hash') == source_hash() and tj.get('batch') == B:
-                    traffic = tj.get('search_kernel_hbm_bytes_per_launch')
-                    valu_insts = tj.get('derived', {}).get('valu_instructions_per_launch')
-                    pmc_src = f'{os.path.relpath(tpath, ROOT)} (rocprofv3 --pmc passes of this command at source hash ' \
-                              f'{tj.get("source_hash")}; not measured by this run)'
-            except Exception:
-                traffic, valu_insts, pmc_src = None, None, None
-        clk_ghz = PEAK_CLOCK_GHZ
-        valu = {'bound': 'valu_issue', 'unit': 'fraction of SIMD issue cycles',
-                'definition': 'VALU wave-instructions per launch x 4 issue cycles / (1024 SIMDs x kernel cycles); kernel '
-                              'cycles = live kernel_ms x peak shader clock',
-                'valu_instructions_per_launch': valu_insts, 'kernel_ms': search_ms, 'shader_clock_ghz': clk_ghz,
-                'achieved': None, 'peak': 1.0, 'frac': None, 'source': pmc_src}
-        if valu_insts:
-            valu['achieved'] = valu_insts * VALU_ISSUE_CYCLES / (SIMDS * search_ms * 1e-3 * clk_ghz * 1e9)
-            valu['frac'] = valu['achieved']
-            # the same instruction count against the whole pipelined step (what `value` is made of): the search kernel's
-            # drain tail and the emit pass are overlapped by the next steps' search passes
-            valu['frac_of_whole_step'] = valu_insts * VALU_ISSUE_CYCLES / (SIMDS * head['ms_per_step'] * 1e-3 * clk_ghz * 1e9)
-        arith = {'f64': 'float64 throughout (stage derivatives, state, cost, verdicts)',
-                 'f32': 'float32 stage derivatives + float64 state accumulators, cost and verdicts'}
-        line = {
-            'metric': 'mpc_solves_per_sec', 'value': head['value'], 'unit': 'solves/s', 'n_gpus': n_gpus,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': head['ms_per_step'],
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': workload_name(B, n_gpus, args.gt),
-                       'per_gpu_batch': B, 'global_batch': B * n_gpus,
-                       'entry_point': f'igt_solve_batch_{args.dtype}',
-                       'arithmetic': arith[args.dtype],
-                       'parallelism': (f'scenario shards x{n_gpus}, one process per GPU, all-gather of u*[:, :, 0] on its own '
-                                       f'stream under the next step') if exchange else 'single GPU',
-                       'ranks_seen': world if exchange else 1, 'backend': backend,
-                       'solves_in_flight': args.in_flight,
-                       'pipelining': (f'step t runs on handle / stream t mod {args.in_flight} (own workspace and output buffers each); '
-                                      f'all {args.steps} steps complete inside the timed region') if args.in_flight > 1 else 'none',
-                       'cost': f'gt_mpc value net V_GT_sc{args.gt} ({len(layers) - 1} hidden layers, identity normalisation)' if args.gt else 'mpc progress cost',
-                       'feasible_fraction': head['feasible']},
-            'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': pmc_src,
-                         'kernel': f'search kernel of igt_solve_batch_{args.dtype} (+ value kernels in gt mode)',
-                         'kernel_ms': search_ms, 'algorithmic_bytes_per_solve': rd + 12,
-                         'note': 'the path is VALU-issue-bound (arithmetic intensity ~1e4 flop/B); see valu_roofline'},
-            'valu_roofline': valu,
-            'kernels_ms': {'search': search_ms, 'emit': emit_ms},
-            'whole_solve_bytes': rd + head['wr'],
-            'precision': {'f64': 'igt_solve_batch_f64: <= 1e-9 of the float64 oracle on every trajectory (curvature '
-                                 'break-point straddlers included)',
-                          'f32': 'igt_solve_batch_f32: <= 1e-5*max(1,|ref|) except trajectories whose curvature switch is '
-                                 'decided inside float32 noise (share measured in tests/test_gpu_parity.py)'},
-        }
-        if tracking is not None:
-            line['tracking_family'] = {
-                'value': tracking['value'], 'unit': 'solves/s', 'ms_per_step': tracking['ms_per_step'], 'dtype': args.dtype,
-                'kernels_ms': {'search': tracking['search_ms'], 'emit': tracking['emit_ms']},
-                'feasible_fraction': tracking['feasible'],
-                'note': 'same batch, entry point and timing with cand_mode = IGT_CAND_TRACK (256 candidates, one pass): '
-                        'the default family of MPC_Planner and igtmpc.evaluate'}
-        if other is not None:
-            line[f'{other_dtype}_path'] = {
-                'value': other['value'], 'unit': 'solves/s', 'ms_per_step': other['ms_per_step'], 'dtype': other_dtype,
-                'entry_point': f'igt_solve_batch_{other_dtype}', 'arithmetic': arith[other_dtype],
-                'kernels_ms': {'search': other['search_ms'], 'emit': other['emit_ms']},
-                'steps': args.steps, 'warmup': args.warmup, 'feasible_fraction': other['feasible'],
-                'note': 'same workload, same run, timed exactly like the headline'}
-        if serial is not None:
-            line['one_solve_in_flight'] = {
-                'value': serial['value'], 'ms_per_step': serial['ms_per_step'], 'dtype': args.dtype,
-                'note': 'same workload and entry point with --in-flight 1: step t+1 is enqueued behind step t on one stream, '
-                        'so every emit pass and every search drain tail is exposed'}
-        if same_work is not None:
-            line['same_per_gpu_work_as_n1'] = {
-                'per_gpu_batch': same_work['B'], 'value': same_work['value'], 'ms_per_step': same_work['ms_per_step'],
-                'note': 'BASELINE configs[1] batch per GPU, for a weak-scaling comparison against the N=1 line'}
-        if n_gpus == 1 and not args.no_cpu_baseline and not args.gt:
-            line['cpu_baseline'] = cpu_baseline(head['batch'], N, C)
+        n_layers = len(shipped_value_net(args.gt)['layers']) if args.gt else 0
+        line = assemble_line(args, head, n_gpus, world, backend, exchange, other=other, serial=serial, tracking=tracking,
+                             same_work=same_work, configs=configs, cpu=cpu, n_layers=n_layers)
+        line['config']['settle_steps'] = head['settle_steps']
         print(json.dumps(line), flush=True)
     if exchange:
         dist.barrier()

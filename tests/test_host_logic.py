@@ -190,6 +190,39 @@ def test_bench_gpus_2_without_torchrun_variables_spawns_two_ranks():
     assert line['ranks_seen'] == 2 and line['tokens'] == [0, 1] and line['spawned_by_bench'] is True
 
 
+def test_bench_multi_gpu_gt_line_is_assembled_without_a_gpu():
+    """`bench.py --gpus N --gt 1` must emit the configs[4] line.  (a) two gloo ranks spawned by
+    bench.py itself assemble the real line from placeholder measurements; (b) the N = 8 line through the same pure
+    function: workload name, per-GPU batch 65 536, ranks seen, backend, no CPU baseline, null PMC fields."""
+    import argparse
+    import importlib.util
+    import json
+    r = _run_bench('--gpus', '2', '--gt', '1', '--rehearse-cpu')
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['ranks_seen'] == 2 and line['n_gpus'] == 2 and line['max_over_ranks_s'] == 2.0
+    assert 'configs[4]' in line['config']['workload'] and line['config']['per_gpu_batch'] == 65536
+    assert line['config']['global_batch'] == 131072 and line['config']['ranks_seen'] == 2 and line['config']['backend'] == 'gloo'
+    assert 'V_GT_sc1' in line['config']['cost'] and 'cpu_baseline' not in line and line['scaling'] == 'weak'
+    spec = importlib.util.spec_from_file_location('bench_mod3', os.path.join(ROOT, 'bench.py'))
+    bm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bm)
+    for gt, B in ((1, 65536), (0, 32768)):
+        args = argparse.Namespace(dtype='f64', gt=gt, cand='lattice', steps=20, warmup=5, settle_ms=150.0, in_flight=4)
+        m = lambda Bm, F=4: dict(dtype='f64', B=Bm, elapsed=1.0, steps=20, value=Bm * 8 * 20 / 1.0, ms_per_step=50.0, search_ms=3.6,
+                                 emit_ms=0.13, lane_search_ms=4.0, lane_emit_ms=0.2, rd=452, wr=1512, feasible=0.78, in_flight=F)
+        line = bm.assemble_line(args, m(B), n_gpus=8, world=8, backend='nccl', exchange=True, serial=m(B, 1),
+                                same_work=None if gt else m(4096), n_layers=3 if gt else 0)
+        assert line['n_gpus'] == 8 and line['config']['ranks_seen'] == 8 and line['config']['global_batch'] == 8 * B
+        assert ('configs[4]' if gt else 'configs[3]') in line['config']['workload']
+        assert (line.get('same_per_gpu_work_as_n1') is None) == bool(gt)
+        assert line['roofline']['bound'] == 'hbm' and line['roofline']['kernel_ms'] == 3.6
+        assert abs(line['roofline']['achieved'] - (452 + 12) * B / 3.6e-3 / 1e9) < 1e-9
+        assert 'one solve in flight' in line['roofline']['regime'] and line['pipelined']['solves_in_flight'] == 4
+        assert line['valu_roofline']['bound'] == 'valu_busy'
+        json.dumps(line)
+
+
 def test_bench_refuses_a_multi_gpu_line_it_cannot_measure():
     import torch
     if torch.cuda.device_count() >= 2:
@@ -223,6 +256,9 @@ def test_bench_names_the_configuration_it_runs():
     bm = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bm)
     assert [bm.default_batch(n) for n in (1, 2, 4, 8)] == [4096, 4096, 4096, 32768]
+    assert [bm.default_batch(n, 1) for n in (1, 8)] == [65536, 65536]          # configs[4]: 65 536 per GPU at any N
+    assert 'configs[4]' in bm.workload_name(65536, 8, 1) and 'x8 GPUs' in bm.workload_name(65536, 8, 1)
+    assert 'tracking candidates' in bm.workload_name(4096, 1, 0, 'track')
     assert 'configs[1]' in bm.workload_name(4096, 1, 0) and 'batch=4096' in bm.workload_name(4096, 1, 0)
     assert 'configs[2]' in bm.workload_name(65536, 1, 0)
     assert 'configs[3]' in bm.workload_name(32768, 8, 0) and '262144' in bm.workload_name(32768, 8, 0)
@@ -291,7 +327,7 @@ def test_design_cites_profiles_that_exist_and_belong_together():
     spec.loader.exec_module(bm)
     if bm.source_hash() != m.group(1):      # kernels changed since the profiles were collected: bench.py prints null PMC fields
         warnings.warn(f'profiles/ were collected at {m.group(1)}, the kernel sources are now {bm.source_hash()}: '
-                      f're-run tools/r02_collect.sh + tools/r02_publish.py')
+                      f're-run tools/collect.sh + tools/publish.py')
 
 
 def test_value_net_from_config_reads_the_reference_yaml_shape(tmp_path):

@@ -4,7 +4,7 @@
 #   usage: tools/pmc_collect.sh <tag> [bench.py args...]
 set -e
 TAG=${1:-pmc}; shift || true
-ARGS="${@:---steps 20 --warmup 3 --no-cpu-baseline --no-secondary --in-flight 1}"
+ARGS="${@:---steps 20 --warmup 3 --no-cpu-baseline --no-secondary --no-configs --in-flight 1 --settle-ms 0}"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -69,12 +69,27 @@ def main(root):
         clk = d.get('shader_clock_GHz_during_search', 2.23)
         simd_cycles = 1024.0 * g(f'{SF}.dur_ns.pmc3') * clk
         d['simd_valu_busy_fraction'] = 4.0 * g(f'{SF}.SQ_ACTIVE_INST_VALU.pmc3') / simd_cycles     # SQ_* are quad-cycles
+        # cycles the vector ALU is busy per VALU wave-instruction, from the counters alone (a v_fma_f64 holds it longer
+        # than the 4 cycles of a 32-bit operation; tools/valu_microbench.hip has the per-opcode rates)
+        d['busy_cycles_per_valu_instruction'] = 4.0 * g(f'{SF}.SQ_ACTIVE_INST_VALU.pmc3') / g(f'{SF}.SQ_INSTS_VALU.pmc3')
+        d['search_kernel_ms'] = g(f'{SF}.dur_ns.pmc3') * 1e-6
         # instruction-based issue fraction: VALU wave-instructions x 4 issue cycles / (SIMDs x kernel cycles)
         d['valu_issue_fraction_4_cycles_per_instruction'] = 4.0 * g(f'{SF}.SQ_INSTS_VALU.pmc3') / simd_cycles
         d['mean_waves_resident_per_simd'] = 4.0 * g(f'{SF}.SQ_WAVE_CYCLES.pmc3') / simd_cycles
         wc = g(f'{SF}.SQ_WAVE_CYCLES.pmc3')
         d['wave_cycles_split'] = {'active': g(f'{SF}.SQ_ACTIVE_INST_ANY.pmc3') / wc,
                                   'issue_stall': g(f'{SF}.SQ_WAIT_INST_ANY.pmc3') / wc}
+    mb = os.environ.get('IGT_PMC_MICROBENCH')
+    if mb and os.path.exists(mb):      # issue rates measured on the same box, 2 waves per SIMD (the search kernels' residency)
+        import re
+        rates = {}
+        for l in open(mb):
+            m = re.match(r'^(.+?)\s+waves/SIMD=2\s+[\d.]+ ms\s+[\d.]+ wave-instr/cycle/SIMD @2.4GHz\s+\(([\d.]+) cycles per wave-instr\)', l)
+            if m:
+                rates[m.group(1).strip()] = float(m.group(2))
+        if rates:
+            d['microbenchmark_cycles_per_instruction'] = dict(rates, note='tools/valu_microbench.hip at 2 waves per SIMD, cycles '
+                                                              'counted at an assumed 2.4 GHz')
     out['derived'] = d
     # the kernel sources this profile belongs to (bench.py quotes PMC figures only at a matching hash)
     import hashlib
