@@ -68,10 +68,14 @@ __device__ __forceinline__ void rotate(double& s, double& c, double sd, double c
     const double c_ = fma(c, cd, -(s * sd));
     s = s_; c = c_;
 }
-template <bool HI_ORDER>
+// NRK: the number of RK4 sub-steps per control step as a compile-time constant (4: what evaluate.py:109,440 passes), or 0:
+// read from the parameters at run time.  With it fixed the generic sub-step loops vanish from the kernel and so does the
+// register pressure they add: the control step of a straight route is 410 instructions instead of 464 (ISA count).
+template <bool HI_ORDER, int NRK = 0>
 struct Fast64 {
     double h, hh, h6, kv, inv_lr, lr_ratio, b0, b1, dt;
     int n_rk4;
+    __device__ __forceinline__ int nrk() const { return NRK > 0 ? NRK : n_rk4; }
 
     __device__ __forceinline__ void init(const KP& P, double b0_, double b1_, double kv_) {
         h = P.h; hh = P.h / 2; h6 = P.h / 6;
@@ -212,10 +216,10 @@ struct Fast64 {
     // the n_rk4 sub-steps of one variant; the reference's discretisation (4) is unrolled: no loop-carried register copies
     template <int MODE>
     __device__ __forceinline__ void run(const StepConst& sc, Work& w) const {
-        if (n_rk4 == 4) {
+        if (NRK == 4 || (NRK == 0 && n_rk4 == 4)) {
             substep<MODE>(sc, w); substep<MODE>(sc, w); substep<MODE>(sc, w); substep<MODE>(sc, w);
         } else {
-            for (int j = 0; j < n_rk4; ++j) substep<MODE>(sc, w);
+            for (int j = 0; j < nrk(); ++j) substep<MODE>(sc, w);
         }
     }
 
@@ -255,7 +259,7 @@ struct Fast64 {
             run<0>(sc, w);
             return;
         }
-        for (int j = 0; j < n_rk4; ++j) {
+        for (int j = 0; j < nrk(); ++j) {
             // travel bound of this sub-step: |o| <= h |ds| <= 2 h (|v| + |h a|)
             const double m = (2.0 * h) * (fabs(w.v1) + 2.0 * fabs(ha));
             const bool clear = (w.d0 + m < 0.0) | (w.d1 - m > 0.0);
@@ -328,7 +332,7 @@ __device__ __forceinline__ void fill_steer_table(const KP& P, const Scenario<dou
     __syncthreads();
 }
 
-template <int CAND, bool HI_ORDER, bool BOOK, bool UNIFORM, class Sink, bool EARLY_EXIT = false, bool STAB = false>
+template <int CAND, bool HI_ORDER, bool BOOK, bool UNIFORM, class Sink, bool EARLY_EXIT = false, bool STAB = false, int NRK = 0>
 __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>& S, int cidx,
                                             const double* __restrict__ table, const double* __restrict__ cinf,
                                             Sink& sink, double& Jout, unsigned& vout, double& sN, double& vN,
@@ -337,7 +341,7 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
     // search only needs feasible-or-not: |ey|, box v and collision are folded into one running maximum, compared with
     // the tolerance when it is read (x > tol for some x  <=>  max x > tol; a NaN operand is ignored by both forms)
     constexpr bool LEAN = BOOK && EARLY_EXIT;
-    typedef Fast64<HI_ORDER> FP;
+    typedef Fast64<HI_ORDER, NRK> FP;
     FP fp;
     fp.init(P, S.b0, S.b1, S.kv);
     double x = S.x0[0], y = S.x0[1], s = S.x0[2], ey = S.x0[3], ep = S.x0[4], v = S.x0[5], psi = S.x0[6];
@@ -360,6 +364,10 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
     typename FP::Work w;
     w.d0 = w.d1 = 0.0;
     sincos_reduced(S.x0[6], w.s2, w.c2);       // carried as (sin,cos)(psi + beta_k); beta_{-1} = 0
+    // (sin,cos)(epsi + beta_k) is carried the same way: the sub-steps turn the pair by exactly the angle epsi advances by
+    // (substep(): h w2 - corr per sub-step), so after control step k-1 it holds (sin,cos)(epsi_k + beta_{k-1}) and step k
+    // turns it by beta_k - beta_{k-1} -- no sincos(epsi) per control step (39 of ~460 instructions on a straight route)
+    sincos_reduced(S.x0[4], w.s1, w.c1);
     double cb_prev = 1.0, sb_prev = 0.0;
 
     for (int k = 0; k < P.N; ++k) {
@@ -415,9 +423,6 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
         // unused on straight routes; with one scenario per lane the votes of substeps() read them on every lane
         // (a straight route's break-points are +inf: d = -inf, "clear")
         if (!UNIFORM || fp.kv != 0.0) { w.d0 = s - fp.b0; w.d1 = s - fp.b1; }
-        // (sin,cos)(epsi): heading errors beyond pi/4 are rare, the range reduction is skipped when no lane needs it
-        if (__all(fabs(ep) < QUADRANT0)) sincos_kernel(ep, w.s1, w.c1);
-        else sincos_reduced(ep, w.s1, w.c1);
         if (BOOK && UNIFORM && EARLY_EXIT) {
             // search only: once every candidate of the slice has failed a verdict, nothing rolled further can win
             const bool lost = (viol != 0) | (LEAN && gmax > P.tol);
@@ -431,15 +436,17 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
                 else if (g > P.tol) viol |= VIOL_COLLISION;
             }
         }
-        rotate(w.s1, w.c1, sb, cb);                                                  // (sin,cos)(beta + epsi)
-        // (sin,cos)(psi + beta_k) from (psi + beta_{k-1}): rotate by beta_k - beta_{k-1}, re-normalise
+        // (sin,cos)(psi + beta_k) from (psi + beta_{k-1}), and (sin,cos)(epsi + beta_k) from (epsi + beta_{k-1}): rotate by
+        // beta_k - beta_{k-1}, re-normalise (first order: the pairs are within rounding of unit length)
         {
             const double sdb = fma(sb, cb_prev, -(cb * sb_prev));
             const double cdb = fma(cb, cb_prev, sb * sb_prev);
             rotate(w.s2, w.c2, sdb, cdb);
-            const double nn = fma(w.s2, w.s2, w.c2 * w.c2);
-            const double r = fma(nn, -0.5, 1.5);
-            w.s2 *= r; w.c2 *= r;
+            rotate(w.s1, w.c1, sdb, cdb);
+            const double r2 = fma(fma(w.s2, w.s2, w.c2 * w.c2), -0.5, 1.5);
+            const double r1 = fma(fma(w.s1, w.s1, w.c1 * w.c1), -0.5, 1.5);
+            w.s2 *= r2; w.c2 *= r2;
+            w.s1 *= r1; w.c1 *= r1;
             cb_prev = cb; sb_prev = sb;
         }
         w.acc_s = 0.0; w.acc_ey = 0.0; w.acc_ep = 0.0; w.acc_x = 0.0; w.acc_y = 0.0; w.acc_psi = 0.0;

@@ -1,0 +1,190 @@
+// igt_kernels_common.h -- device code shared by the kernel translation units (igt_kernels.hip: float path, value network,
+// forecast, model steps; igt_kernels_f64.hip: the float64 search / emit / rollout-all kernels): scenario loading, the
+// trajectory sink, the per-XCD work queues and the persistent-wave loop.
+#pragma once
+#include "igt_device.h"
+#include "igt_launch.h"
+
+namespace igt {
+
+template <typename T>
+__device__ __forceinline__ void load_scenario(Scenario<T>& S, const KP& P, int b, const T* __restrict__ x0,
+                                              const T* __restrict__ u_prev, const T* __restrict__ kparams,
+                                              const uint32_t* __restrict__ flags, const T* __restrict__ obs,
+                                              Centre<T> cpar = Centre<T>{nullptr, nullptr}) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) S.x0[i] = (double)x0[(size_t)b * 7 + i];
+    // ego routes '32','41' use |heading| (mpc.py:231-234, 282-285)
+    if (flags[b] & 1u) S.x0[6] = fabs(S.x0[6]);
+    S.a_prev = (double)u_prev[(size_t)b * 2 + 0];
+    S.df_prev = (double)u_prev[(size_t)b * 2 + 1];
+    S.b0 = (double)kparams[(size_t)b * 3 + 0];
+    S.b1 = (double)kparams[(size_t)b * 3 + 1];
+    S.kv = (double)kparams[(size_t)b * 3 + 2];
+    S.obs = obs + (size_t)b * P.n_obs * 2 * (P.N + 1);
+    // ramp-hold targets = base sequence + offset.  Base: the warm start u_ws[b] (the previous solution shifted by one
+    // step, utils.py:354-363 augment_prev_sol) when the scenario carries one (IGT_FLAG_WARM), else u_prev held.
+    S.ws = (cpar.ws && (flags[b] & 2u)) ? cpar.ws + (size_t)b * 2 * P.N : nullptr;
+    if (cpar.cpar) {     // refinement pass: centre offset / span chosen by refine_targets_kernel
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S.cpar[i] = cpar.cpar[(size_t)b * 4 + i];
+    } else {             // first pass: offsets centred on 0, span = what the rate limits reach over the horizon
+        S.cpar[0] = 0.0; S.cpar[1] = 0.0;
+        S.cpar[2] = P.N * P.rate_a; S.cpar[3] = P.cand_mode == CAND_TRACK ? P.trk_span : P.N * P.rate_df;
+    }
+}
+
+__device__ __forceinline__ bool finite_d(double x) { return fabs(x) < 1.79e308; }
+
+template <typename T>
+struct StoreSink {
+    static constexpr bool kKeepsStates = true;
+    T* x;   // [7, N+1] of this scenario/candidate (may be null)
+    T* u;   // [2, N]
+    int N;
+    __device__ __forceinline__ void ctrl(int, int k, double a, double df) {
+        if (u) { u[k] = (T)a; u[N + k] = (T)df; }
+    }
+    __device__ __forceinline__ void state(int, int k, const double (&st)[7]) {
+        if (x) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) x[i * (N + 1) + k] = (T)st[i];
+        }
+    }
+};
+
+// Scenario j of queue q.  Blocks of 8 consecutive scenarios are dealt to the 8 queues rotated by the block index, so
+// that a batch whose make-up repeats with a period of 8 (the benchmark's does: route pair and ego index are functions
+// of b mod 64) does not give one XCD all the turning routes: measured 30 % spread between the queues' finishing times
+// with b mod 8, a few % with the rotation.  b >= B marks a hole in the last block.
+__device__ __forceinline__ int queue_scenario(int q, int j) { return 8 * j + ((q - j) & 7); }
+
+// Longest units first (small batches).  A unit's wall time is what the tail of the search kernel is made of, and units
+// differ 8x (16 .. 130 us at 2 waves per SIMD).  What the traces (tools/trace_units.py) and the oracle-side analysis
+// (tools/death_steps.py) show to matter:
+//   * the centre-steering slice runs (nearly) the whole horizon; the others leave through the early exit after a
+//     number of steps that falls with the speed (|e_y| grows with v: 18 steps at v0 < 1 m/s, 9 at v0 > 4);
+//   * a scenario that meets its arc within the horizon rolls the long sub-step variants (about 1.9x per step).
+// One workgroup per queue sorts its units into QC cost classes, most expensive first, keeping the scenario order
+// inside a class (a stable counting sort, so the order is a function of the inputs alone).
+// order[q][k] = (scenario ordinal in the queue) * 256 + slice.
+constexpr int QC = 8, QB_THREADS = 1024, QB_TRIPS = 2;     // up to 2048 units per queue (B <= 8192 at W = 2)
+template <typename T>
+__global__ __launch_bounds__(QB_THREADS) void build_queues_kernel(KP P, int B, int W, const T* __restrict__ x0,
+                                                                  const T* __restrict__ kparams,
+                                                                  unsigned* __restrict__ order, int stride,
+                                                                  unsigned* __restrict__ work_counter) {
+    __shared__ int cnt[QB_TRIPS][QB_THREADS / 64][QC];   // [trip][wave][class] counts, then exclusive offsets
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) work_counter[q * 64] = 0u;             // this queue's unit counter (saves the memset node)
+    const int n_scen = (B + 7) / 8, n = n_scen * W;
+    int cls[QB_TRIPS], rank[QB_TRIPS];
+#pragma unroll
+    for (int t = 0; t < QB_TRIPS; ++t) {
+        const int i = t * QB_THREADS + tid;
+        int c = -1;
+        if (i < n) {
+            const int j = i / W, p = i - j * W, b = queue_scenario(q, j);
+            c = QC - 1;                                  // a hole of the last block of 8: sorts last, skipped by the search
+            if (b < B) {
+                const float s0 = (float)x0[(size_t)b * 7 + 2], v0 = (float)x0[(size_t)b * 7 + 5];
+                const float b0 = (float)kparams[(size_t)b * 3 + 0], b1 = (float)kparams[(size_t)b * 3 + 1], kv = (float)kparams[(size_t)b * 3 + 2];
+                const float reach = s0 + 1.5f * fmaxf(v0, 1.0f) * (float)(P.N * P.dt);
+                const bool arc = kv != 0.0f && reach >= b0 && s0 <= b1;
+                const float frac = p == 0 ? 0.95f : fminf(fmaxf(1.05f - 0.15f * v0, 0.4f), 0.95f);   // share of the horizon rolled
+                const float cost = frac * (arc ? 1.9f : 1.0f);                                        // 0.4 .. 1.8
+                c = (int)((1.85f - cost) * ((float)QC / 1.5f));
+                c = c < 0 ? 0 : (c > QC - 1 ? QC - 1 : c);
+            }
+        }
+        cls[t] = c; rank[t] = 0;
+#pragma unroll
+        for (int cc = 0; cc < QC; ++cc) {
+            const unsigned long long m = __ballot(c == cc);
+            if (lane == 0) cnt[t][wv][cc] = __popcll(m);
+            if (c == cc) rank[t] = __popcll(m & ((1ull << lane) - 1ull));
+        }
+    }
+    __syncthreads();
+    __shared__ int total[QC];
+    if (tid < QC) {          // per class: exclusive offsets in index order (trip, wave), and the class total
+        int run = 0;
+        for (int t = 0; t < QB_TRIPS; ++t)
+            for (int w2 = 0; w2 < QB_THREADS / 64; ++w2) { const int v = cnt[t][w2][tid]; cnt[t][w2][tid] = run; run += v; }
+        total[tid] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < QB_TRIPS; ++t) {
+        if (cls[t] < 0) continue;
+        int off = cnt[t][wv][cls[t]] + rank[t];
+        for (int cc = 0; cc < cls[t]; ++cc) off += total[cc];      // the more expensive classes come first
+        const int i = t * QB_THREADS + tid, j = i / W, p = i - j * W;
+        order[(size_t)q * stride + off] = (unsigned)j * 256u + (unsigned)p;
+    }
+}
+
+// Persistent waves, one per workgroup.  Replacing a retired single-unit workgroup costs tens of microseconds of idle
+// wave slot on this part (measured: 2 of 3 slots occupied on average) and unit durations differ 3x (early exit,
+// straight vs arc), so the waves loop, taking units from counters until none is left.  A returning device-scope
+// atomic on ONE address retires every ~11.4 ns on MI355X (tools/atomic_probe.hip; the XCDs' L2s are not coherent,
+// so it executes memory-side): a single counter would cap the kernel at 44 M solves/s and queue the waves of a
+// small batch behind each other.  Hence one counter per XCD (workgroup n runs on XCD n mod 8), 256 B apart; queue q
+// owns one scenario of every block of 8 (queue_scenario) and deals them out scenario-major, or longest first when
+// the batch is small (build_queues_kernel); a wave whose queue is dry takes from the other queues in turn.
+// `unit(b, p)` rolls slice p of scenario b (float path: search_unit, 128 candidates; double path: search_unit64, 64).
+template <class Unit>
+__device__ __forceinline__ void search_waves(const KP& P, int B, int W, int queues, unsigned* __restrict__ work_counter,
+                                             const unsigned* __restrict__ order, int order_stride, const Unit& unit) {
+    const unsigned q = blockIdx.x % (unsigned)queues, uW = (unsigned)W;
+    const unsigned n_scen = ((unsigned)B + 7u) / 8u;          // blocks of 8 scenarios; queue q takes one of each
+    const unsigned K = n_scen * uW;
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    const unsigned hold = ((P.dev >> 12) & 15u ? (P.dev >> 12) & 15u : 4u) * (gridDim.x / (unsigned)queues + 1u);
+    const unsigned late_from = K > hold ? K - hold : 0u;
+    // own queue first, then the other XCDs' queues in turn (the XCDs are not equally fast: one of the eight took 10 %
+    // longer over the same work in every trace).  Item k of a queue is scenario ordinal j and slice p, through the
+    // longest-first order when one was built.
+    // The next index is fetched while the current unit is rolled -- but an index taken is an item reserved: towards the
+    // end of a queue a wave in a long unit would sit on an item that idle waves could run (measured at B = 4096: waves
+    // started leaving at 60 % of the kernel's span with items still held; units last 16 .. 130 us).  So over the last
+    // four items per wave of the queue, and when stealing, the index is fetched only when the wave is ready for it.
+    for (unsigned d = 0; d < (unsigned)queues; ++d) {
+        const unsigned qq = (q + d) % (unsigned)queues;
+        if (d > 0 && (P.dev & 512)) break;    // developer switch: no stealing
+        unsigned* counter = work_counter + qq * 64u;
+        const unsigned* ord = order ? order + (size_t)qq * order_stride : nullptr;
+        unsigned k = 0, item = 0;
+        if (lane0) {
+            k = atomicAdd(counter, 1u);
+            item = (ord && k < K) ? ord[k] : 0u;
+        }
+        k = __builtin_amdgcn_readfirstlane(k);
+        item = __builtin_amdgcn_readfirstlane(item);
+        while (k < K) {                       // every wave gets there: the counters only grow
+            unsigned nxt = 0, nxt_item = 0;
+            const bool early = d == 0 && k < late_from;
+            if (early && lane0) {
+                nxt = atomicAdd(counter, 1u);
+                nxt_item = (ord && nxt < K) ? ord[nxt] : 0u;
+            }
+            const unsigned j = ord ? item >> 8 : k / uW, p = ord ? item & 255u : k - (k / uW) * uW;
+            const unsigned long long t0 = (P.dev & 256) ? wall_clock64() : 0ull;
+            const int b = queue_scenario((int)qq, (int)j);
+            if (b < B) unit(b, (int)p);
+            if ((P.dev & 256) && lane0) {      // developer trace (IGT_DEV_TRACE): when each unit ran, and where
+                unsigned long long* tr =
+                    reinterpret_cast<unsigned long long*>(work_counter + 1024) + ((size_t)qq * order_stride + k) * 4;
+                tr[0] = t0; tr[1] = wall_clock64(); tr[2] = blockIdx.x; tr[3] = ((unsigned long long)j << 8) | p;
+            }
+            if (!early && lane0) {
+                nxt = atomicAdd(counter, 1u);
+                nxt_item = (ord && nxt < K) ? ord[nxt] : 0u;
+            }
+            k = __builtin_amdgcn_readfirstlane(nxt);
+            item = __builtin_amdgcn_readfirstlane(nxt_item);
+        }
+    }
+}
+
+}  // namespace igt

@@ -1,0 +1,566 @@
+// igt_kernels_f64.hip -- gfx950 kernels of the float64 entry points (the reference's precision) and their launchers:
+//   search_f64_kernel_*   persistent waves, one 64-candidate steering slice of one scenario per unit (igt_fast64.h)
+//   emit_f64_kernel       one lane per scenario: the winner re-rolled with the same arithmetic -> x*[7,N+1], u*[2,N]
+//   rollout_all_f64_kernel   debug / parity: every candidate's trajectory, cost and verdict bits
+//   search_kernel / emit_kernel / rollout_all_kernel<ExactStepper<double>>   the oracle's operation order (IGT_DEV_FLAGS=1024)
+//   search_literal_f64_kernel   the literal north_star mapping, a measurement variant (IGT_DEV_FLAGS=2048)
+// Compiled on its own so that the two heavy translation units build in parallel.
+#include "igt_device.h"
+#include "igt_fast64.h"
+#include "igt_launch.h"
+#include "igt_kernels_common.h"
+
+namespace igt {
+
+template <class Stepper, typename T, int NC, bool SHARED_DF, bool VALUE>
+__global__ __launch_bounds__(256) void search_kernel(KP P, int B, const T* __restrict__ x0,
+                                                     const T* __restrict__ u_prev,
+                                                     const T* __restrict__ kparams,
+                                                     const uint32_t* __restrict__ flags,
+                                                     const T* __restrict__ obs,
+                                                     const double* __restrict__ table,
+                                                     const double* __restrict__ cinf, Centre<T> cpar,
+                                                     T* __restrict__ cost_out, int32_t* __restrict__ argmin_out,
+                                                     int32_t* __restrict__ status_out, T* __restrict__ rec_sN,
+                                                     T* __restrict__ rec_vN, double* __restrict__ rec_J,
+                                                     uint32_t* __restrict__ rec_viol) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;  // wave-uniform
+    const int lane = threadIdx.x & 63;
+    Scenario<T> S;
+    load_scenario<T>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
+
+    double bestJ = 0.0;
+    int bestC = -1;
+    NullSink sink;
+    const int passes = P.C / (64 * NC);
+    for (int p = 0; p < passes; ++p) {
+        int cidx[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) cidx[q] = (p * NC + q) * 64 + lane;
+        double J[NC], sN[NC], vN[NC];
+        unsigned viol[NC];
+        rollout_pass<Stepper, NC, SHARED_DF, T>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
+        if (VALUE) {   // terminal value network: leave the terminal term to value_kernel (mpc.py:369)
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const size_t idx = (size_t)b * P.C + cidx[q];
+                rec_sN[idx] = (T)sN[q]; rec_vN[idx] = (T)vN[q]; rec_J[idx] = J[q]; rec_viol[idx] = viol[q];
+            }
+            continue;
+        }
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const double Jq = J[q] - (sN[q] - S.x0[2]);  // mpc.py:372
+            const bool ok = (viol[q] == 0) && finite_d(Jq);
+            // candidates arrive in increasing index per lane: strict '<' keeps the lowest index
+            if (ok && (bestC < 0 || Jq < bestJ)) { bestJ = Jq; bestC = cidx[q]; }
+        }
+    }
+    // wave butterfly arg-min, ties -> lowest candidate index
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double oJ = __shfl_xor(bestJ, off, 64);
+        const int oC = __shfl_xor(bestC, off, 64);
+        const bool take = (oC >= 0) && (bestC < 0 || oJ < bestJ || (oJ == bestJ && oC < bestC));
+        if (take) { bestJ = oJ; bestC = oC; }
+    }
+    if (VALUE) return;
+    if (lane == 0) {
+        cost_out[b] = bestC >= 0 ? (T)bestJ : (T)INFINITY;
+        argmin_out[b] = bestC;
+        status_out[b] = bestC >= 0 ? 0 : 1;
+    }
+}
+
+template <class Stepper, typename T>
+__global__ __launch_bounds__(64) void emit_kernel(KP P, int B, const T* __restrict__ x0,
+                                                  const T* __restrict__ u_prev, const T* __restrict__ kparams,
+                                                  const uint32_t* __restrict__ flags, const T* __restrict__ obs,
+                                                  const double* __restrict__ table,
+                                                  const double* __restrict__ cinf, Centre<T> cpar,
+                                                  const int32_t* __restrict__ argmin, T* __restrict__ x_out,
+                                                  T* __restrict__ u_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    T* xo = x_out + (size_t)b * 7 * (P.N + 1);
+    T* uo = u_out + (size_t)b * 2 * P.N;
+    const int c = argmin[b];
+    if (c < 0) {  // is_opt False (mpc.py:402-406): no trajectory
+        const T nan = (T)NAN;
+        for (int i = 0; i < 7 * (P.N + 1); ++i) xo[i] = nan;
+        for (int i = 0; i < 2 * P.N; ++i) uo[i] = nan;
+        return;
+    }
+    Scenario<T> S;
+    load_scenario<T>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
+    StoreSink<T> sink{xo, uo, P.N};
+    const int cidx[1] = {c};
+    double J[1], sN[1], vN[1];
+    unsigned viol[1];
+    rollout_pass<Stepper, 1, false, T>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
+}
+
+template <class Stepper, typename T>
+__global__ __launch_bounds__(256) void rollout_all_kernel(KP P, int B, const T* __restrict__ x0,
+                                                          const T* __restrict__ u_prev,
+                                                          const T* __restrict__ kparams,
+                                                          const uint32_t* __restrict__ flags,
+                                                          const T* __restrict__ obs,
+                                                          const double* __restrict__ table,
+                                                          const double* __restrict__ cinf, Centre<T> cpar, T* __restrict__ X_all,
+                                                          T* __restrict__ U_all, T* __restrict__ cost_all,
+                                                          uint32_t* __restrict__ viol_all, T* __restrict__ rec_sN,
+                                                          T* __restrict__ rec_vN, double* __restrict__ rec_J,
+                                                          uint32_t* __restrict__ rec_viol) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    Scenario<T> S;
+    load_scenario<T>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
+    for (int c = lane; c < P.C; c += 64) {
+        const size_t bc = (size_t)b * P.C + c;
+        StoreSink<T> sink{X_all ? X_all + bc * 7 * (P.N + 1) : nullptr, U_all ? U_all + bc * 2 * P.N : nullptr, P.N};
+        const int cidx[1] = {c};
+        double J[1], sN[1], vN[1];
+        unsigned viol[1];
+        rollout_pass<Stepper, 1, false, T>(P, S, cidx, table, cinf, sink, J, viol, sN, vN);
+        if (rec_J) {   // value-net cost: value_kernel adds the terminal term and fills cost_all / viol_all
+            rec_sN[bc] = (T)sN[0]; rec_vN[bc] = (T)vN[0]; rec_J[bc] = J[0]; rec_viol[bc] = viol[0];
+            continue;
+        }
+        const double Jq = J[0] - (sN[0] - S.x0[2]);
+        if (!finite_d(Jq)) viol[0] |= VIOL_NONFINITE;
+        cost_all[bc] = (T)Jq;
+        viol_all[bc] = viol[0];
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// float64 path (igt_fast64.h): one candidate per lane, W = C/64 units per scenario
+// ---------------------------------------------------------------------------------------
+// Generated G x G families with W * 64 == C and W | G: unit p takes G/W STEERING values (all G accelerations), handed out
+// from the centre of the range outwards, as the float path does with its 128-candidate slices -- the extreme-steering
+// units fail as a whole within a few steps and leave through the early exit.  Otherwise: chunks of 64 in index order.
+template <int CAND>
+__device__ __forceinline__ bool steering_slices64(const KP& P, int W) {
+    return CAND != CAND_TABLE && P.G * P.G == P.C && W * 64 == P.C && P.G % W == 0 && !(P.dev & 1);
+}
+template <int CAND>
+__device__ __forceinline__ int slice_candidate64(const KP& P, int W, int p, int lane) {
+    if (steering_slices64<CAND>(P, W)) {
+        const int nj = P.G / W, jl = lane % nj, il = lane / nj, r = p * nj + jl;      // il < 64 W / G = G
+        const int j = (r & 1) ? P.G / 2 - 1 - (r >> 1) : P.G / 2 + (r >> 1);
+        return il * P.G + j;
+    }
+    return p * 64 + lane;
+}
+
+#define IGT_SEARCH64_ARGS                                                                                            \
+    KP P, int B, int W, int queues, unsigned* __restrict__ work_counter, const unsigned* __restrict__ order,          \
+        int order_stride, const double* __restrict__ x0, const double* __restrict__ u_prev,                          \
+        const double* __restrict__ kparams, const uint32_t* __restrict__ flags, const double* __restrict__ obs,      \
+        const double* __restrict__ table, const double* __restrict__ cinf, Centre<double> cpar,          \
+        double* __restrict__ part_J, int32_t* __restrict__ part_c, double* __restrict__ rec_sN,                      \
+        double* __restrict__ rec_vN, double* __restrict__ rec_J, uint32_t* __restrict__ rec_viol,                    \
+        unsigned* __restrict__ rec_count, int32_t* __restrict__ rec_b, int2* __restrict__ unit_seg
+
+// One work unit = one (scenario, 64-candidate slice), rolled by one wave; leaves the slice's best (J, c), or -- value-net
+// cost -- every candidate's record for value_kernel<double> (mpc.py:369).
+template <int CAND, bool HI, bool VALUE, int NRK = 0>
+__device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, const double* __restrict__ x0,
+                                              const double* __restrict__ u_prev, const double* __restrict__ kparams,
+                                              const uint32_t* __restrict__ flags, const double* __restrict__ obs,
+                                              const double* __restrict__ table, const double* __restrict__ cinf,
+                                              Centre<double> cpar, double* __restrict__ part_J,
+                                              int32_t* __restrict__ part_c, double* __restrict__ rec_sN,
+                                              double* __restrict__ rec_vN, double* __restrict__ rec_J,
+                                              uint32_t* __restrict__ rec_viol, unsigned* __restrict__ rec_count,
+                                              int32_t* __restrict__ rec_b, int2* __restrict__ unit_seg) {
+    const int lane = threadIdx.x & 63;
+    Scenario<double> S;
+    load_scenario<double>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
+    NullSink sink;
+    const int c = slice_candidate64<CAND>(P, W, p, lane);
+    double J, sN, vN;
+    unsigned viol;
+    // steering slices of the families with state-independent steering: the slice's G/W steering columns are laid out in
+    // LDS once per unit instead of being recomputed by each of their 64 W/G lanes at every step (igt_fast64.h)
+    constexpr bool TABULATED = CAND == CAND_LATTICE || CAND == CAND_RAMP_HOLD;
+    const int nj = P.G / W;
+    if (TABULATED && steering_slices64<CAND>(P, W) && nj * P.N <= f64::STAB_MAX_ENTRIES && !(P.dev & 4)) {
+        __shared__ double stab[f64::STAB_MAX_ENTRIES * 3];
+        f64::fill_steer_table<CAND>(P, S, nj, p, lane, P.lr_ratio, stab);
+        f64::rollout_one<CAND, HI, true, true, NullSink, true, true, NRK>(P, S, c, table, cinf, sink, J, viol, sN, vN,
+                                                                          stab + (lane % nj) * 3, nj * 3);
+        __syncthreads();                                  // the next unit of this wave rewrites the table
+    } else {
+        f64::rollout_one<CAND, HI, true, true, NullSink, true, false, NRK>(P, S, c, table, cinf, sink, J, viol, sN, vN);
+    }
+    if (VALUE) {   // terminal value network (mpc.py:369): append the feasible candidates for value_mfma_f64_kernel; the
+                   // unit's entries are contiguous, unit_seg remembers where (unit_reduce_kernel picks the unit's best)
+        const bool ok = viol == 0 && finite_d(J);
+        const unsigned long long m = __ballot(ok);
+        const unsigned n = __popcll(m);
+        unsigned base = 0;
+        if (lane == 0 && n) base = atomicAdd(rec_count, n);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (ok) {
+            const unsigned e = base + __popcll(m & ((1ull << lane) - 1ull));
+            rec_b[e] = b; reinterpret_cast<int32_t*>(rec_viol)[e] = c; rec_sN[e] = sN; rec_vN[e] = vN; rec_J[e] = J;
+        }
+        if (lane == 0) unit_seg[b * W + p] = make_int2((int)base, (int)n);
+        return;
+    }
+    const double Jq = J - (sN - S.x0[2]);                       // mpc.py:372
+    double bestJ = Jq;
+    int bestC = ((viol == 0) && finite_d(Jq)) ? c : -1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {                   // wave butterfly arg-min, ties -> lowest candidate index
+        const double oJ = __shfl_xor(bestJ, off, 64);
+        const int oC = __shfl_xor(bestC, off, 64);
+        const bool take = (oC >= 0) && (bestC < 0 || oJ < bestJ || (oJ == bestJ && oC < bestC));
+        if (take) { bestJ = oJ; bestC = oC; }
+    }
+    if (lane == 0) { part_J[b * W + p] = bestJ; part_c[b * W + p] = bestC; }
+}
+
+// persistent waves on the per-XCD queues (search_waves), 2 or 3 per SIMD like the float kernels.  NRK = 4: the build for the
+// reference's discretisation (num_rk4_steps = 4, evaluate.py:109), NRK = 0: any n_rk4 (same arithmetic, same bits)
+template <int CAND, bool HI, bool VALUE, int NRK>
+__global__ __launch_bounds__(64) void search_f64_kernel_o2(IGT_SEARCH64_ARGS) {
+    search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
+        search_unit64<CAND, HI, VALUE, NRK>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN,
+                                       rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg);
+    });
+}
+template <int CAND, bool HI, bool VALUE, int NRK>      // held to 256 registers for the tracking family (see search_fast_kernel_o2w)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void search_f64_kernel_o2w(IGT_SEARCH64_ARGS) {
+    search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
+        search_unit64<CAND, HI, VALUE, NRK>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN,
+                                       rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg);
+    });
+}
+template <int CAND, bool HI, bool VALUE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void search_f64_kernel_o3(IGT_SEARCH64_ARGS) {
+    search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
+        search_unit64<CAND, HI, VALUE>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN,
+                                       rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg);
+    });
+}
+
+// one lane per scenario: final arg-min over the W partials, then the winner re-rolled with the same arithmetic
+// (general sub-step variant: the lanes of the wave belong to different scenarios) -> x*[7,N+1], u*[2,N]
+template <int CAND, bool HI, int NRK>
+__global__ __launch_bounds__(64) void emit_f64_kernel(KP P, int B, int W, const double* __restrict__ x0,
+                                                      const double* __restrict__ u_prev,
+                                                      const double* __restrict__ kparams,
+                                                      const uint32_t* __restrict__ flags, const double* __restrict__ obs,
+                                                      const double* __restrict__ table, const double* __restrict__ cinf,
+                                                      Centre<double> cpar, const double* __restrict__ part_J,
+                                                      const int32_t* __restrict__ part_c, double* __restrict__ cost_out,
+                                                      int32_t* __restrict__ argmin_out, int32_t* __restrict__ status_out,
+                                                      double* __restrict__ x_out, double* __restrict__ u_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double bestJ = 0.0;
+    int c = -1;
+    for (int w = 0; w < W; ++w) {      // (J, c) lexicographic: ties -> lowest candidate index whatever the slice order
+        const int cw = part_c[(size_t)b * W + w];
+        const double Jw = part_J[(size_t)b * W + w];
+        if (cw >= 0 && (c < 0 || Jw < bestJ || (Jw == bestJ && cw < c))) { bestJ = Jw; c = cw; }
+    }
+    cost_out[b] = c >= 0 ? bestJ : (double)INFINITY;
+    argmin_out[b] = c;
+    status_out[b] = c >= 0 ? 0 : 1;
+    double* xo = x_out + (size_t)b * 7 * (P.N + 1);
+    double* uo = u_out + (size_t)b * 2 * P.N;
+    if (c < 0) {  // is_opt False (mpc.py:402-406): no trajectory
+        for (int i = 0; i < 7 * (P.N + 1); ++i) xo[i] = (double)NAN;
+        for (int i = 0; i < 2 * P.N; ++i) uo[i] = (double)NAN;
+        return;
+    }
+    Scenario<double> S;
+    load_scenario<double>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
+    StoreSink<double> sink{xo, uo, P.N};
+    double J, sN, vN;
+    unsigned viol;
+    f64::rollout_one<CAND, HI, false, false, StoreSink<double>, false, false, NRK>(P, S, c, table, cinf, sink, J, viol, sN, vN);
+}
+
+template <int CAND, bool HI>
+__global__ __launch_bounds__(256) void rollout_all_f64_kernel(KP P, int B, const double* __restrict__ x0,
+                                                              const double* __restrict__ u_prev,
+                                                              const double* __restrict__ kparams,
+                                                              const uint32_t* __restrict__ flags,
+                                                              const double* __restrict__ obs,
+                                                              const double* __restrict__ table,
+                                                              const double* __restrict__ cinf, Centre<double> cpar,
+                                                              double* __restrict__ X_all, double* __restrict__ U_all,
+                                                              double* __restrict__ cost_all, uint32_t* __restrict__ viol_all,
+                                                              double* __restrict__ rec_sN, double* __restrict__ rec_vN,
+                                                              double* __restrict__ rec_J, uint32_t* __restrict__ rec_viol) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    Scenario<double> S;
+    load_scenario<double>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
+    for (int c = lane; c < P.C; c += 64) {          // C is a multiple of 64: the wave stays whole (votes inside)
+        const size_t bc = (size_t)b * P.C + c;
+        StoreSink<double> sink{X_all ? X_all + bc * 7 * (P.N + 1) : nullptr, U_all ? U_all + bc * 2 * P.N : nullptr, P.N};
+        double J, sN, vN;
+        unsigned viol;
+        f64::rollout_one<CAND, HI, true, true, StoreSink<double>>(P, S, c, table, cinf, sink, J, viol, sN, vN);
+        if (rec_J) {   // value-net cost: value_kernel adds the terminal term and fills cost_all / viol_all
+            rec_sN[bc] = sN; rec_vN[bc] = vN; rec_J[bc] = J; rec_viol[bc] = viol;
+            continue;
+        }
+        const double Jq = J - (sN - S.x0[2]);
+        if (!finite_d(Jq)) viol |= VIOL_NONFINITE;
+        cost_all[bc] = Jq;
+        viol_all[bc] = viol;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The LITERAL mapping of BASELINE.json's north_star, kept as a measurement variant (IGT_DEV_FLAGS = 2048):
+// one wavefront per (scenario, candidate) trajectory -- lane 0 rolls the horizon (the recurrence is sequential) and
+// stages the states in LDS; then the wave evaluates the stage costs and verdicts stage-parallel (lane k = stage k,
+// terminal-set facets spread over all 64 lanes), butterfly-reduces them, and the 16 waves of the scenario's workgroup
+// take the arg-min over the candidates.  DESIGN.md section 3 has the numbers: the roll-out is 63/64 idle, so this is
+// ~40x slower than one lane per candidate; it is NOT a production path (sum order differs from the oracle's).
+// ---------------------------------------------------------------------------------------
+struct LdsSink {
+    static constexpr bool kKeepsStates = true;
+    double* x;   // [7, N+1]
+    double* u;   // [2, N]
+    int N;
+    __device__ __forceinline__ void ctrl(int, int k, double a, double df) { u[k] = a; u[N + k] = df; }
+    __device__ __forceinline__ void state(int, int k, const double (&st)[7]) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) x[i * (N + 1) + k] = st[i];
+    }
+};
+constexpr int LIT_WAVES = 16, LIT_MAX_N = 40;
+template <int CAND, bool HI>
+__global__ __launch_bounds__(64 * LIT_WAVES) void search_literal_f64_kernel(
+    KP P, int B, int W, const double* __restrict__ x0, const double* __restrict__ u_prev, const double* __restrict__ kparams,
+    const uint32_t* __restrict__ flags, const double* __restrict__ obs, const double* __restrict__ table,
+    const double* __restrict__ cinf, Centre<double> cpar, double* __restrict__ part_J, int32_t* __restrict__ part_c) {
+    __shared__ double lds[LIT_WAVES][9 * (LIT_MAX_N + 1)];
+    __shared__ double wJ[LIT_WAVES];
+    __shared__ int wC[LIT_WAVES];
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    Scenario<double> S;
+    load_scenario<double>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
+    double* X = lds[wave];
+    double* U = X + 7 * (P.N + 1);
+    double bestJ = 0.0;
+    int bestC = -1;
+    for (int c = wave; c < P.C; c += LIT_WAVES) {
+        if (lane == 0) {                       // the trajectory: one lane, the other 63 wait
+            LdsSink sink{X, U, P.N};
+            double J, sN, vN;
+            unsigned viol;
+            f64::rollout_one<CAND, HI, false, true, LdsSink>(P, S, c, table, cinf, sink, J, viol, sN, vN);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        // stage-parallel cost (mpc.py:361-364) and verdicts (mpc.py:296-299, 316-317, 223-226): lane k = stage k
+        double part = 0.0, g = -1.0e300;
+        for (int k = lane; k <= P.N; k += 64) {
+            const double ey = X[3 * (P.N + 1) + k], ep = X[4 * (P.N + 1) + k], v = X[5 * (P.N + 1) + k];
+            part += ep * ep + ey * ey;
+            g = fmax(g, fabs(ey) - P.ey_lim);
+            if (k < P.N) {
+                const double a = U[k], df = U[P.N + k];
+                part += P.w_u * (a * a + df * df);
+                g = fmax(g, fmax(P.v_min - v, v - P.v_max));
+            }
+            if (k >= 1)
+                for (int o = 0; o < P.n_obs; ++o) {
+                    const double dx = X[k] - S.obs[(o * 2 + 0) * (P.N + 1) + k], dy = X[(P.N + 1) + k] - S.obs[(o * 2 + 1) * (P.N + 1) + k];
+                    g = fmax(g, P.dmin2 - (dx * dx + dy * dy));
+                }
+        }
+        {   // terminal set (mpc.py:177-180): the facets over the lanes
+            const double vt = X[5 * (P.N + 1) + P.N - 1], at = U[P.N - 1];
+            for (int m = lane; m < P.F; m += 64) g = fmax(g, cinf[m * 3 + 0] * vt + cinf[m * 3 + 1] * at - cinf[m * 3 + 2]);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            part += __shfl_xor(part, off, 64);
+            g = fmax(g, __shfl_xor(g, off, 64));
+        }
+        const double Jq = part - (X[2 * (P.N + 1) + P.N] - S.x0[2]);          // mpc.py:372
+        if (g <= P.tol && finite_d(Jq) && (bestC < 0 || Jq < bestJ)) { bestJ = Jq; bestC = c; }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) { wJ[wave] = bestJ; wC[wave] = bestC; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double J = 0.0;
+        int c = -1;
+        for (int w = 0; w < LIT_WAVES; ++w)
+            if (wC[w] >= 0 && (c < 0 || wJ[w] < J || (wJ[w] == J && wC[w] < c))) { J = wJ[w]; c = wC[w]; }
+        part_J[(size_t)b * W] = J; part_c[(size_t)b * W] = c;
+        for (int w = 1; w < W; ++w) part_c[(size_t)b * W + w] = -1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------
+template <bool VALUE>
+static hipError_t launch_search_exact(const KP& P, int B, const SolveArgs<double>& A, hipStream_t st) {
+    typedef ExactStepper<double> St;
+    const dim3 grid((B + 3) / 4), block(256);
+    if (P.cand_mode != CAND_TABLE)
+        hipLaunchKernelGGL((search_kernel<St, double, 1, true, VALUE>), grid, block, 0, st, P, B, A.x0, A.u_prev,
+                           A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.cost_out, A.argmin_out, A.status_out,
+                           A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
+    else
+        hipLaunchKernelGGL((search_kernel<St, double, 1, false, VALUE>), grid, block, 0, st, P, B, A.x0, A.u_prev,
+                           A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.cost_out, A.argmin_out, A.status_out,
+                           A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
+    return hipGetLastError();
+}
+
+bool search_builds_queues(const KP& P, int B, const SolveArgs<double>& A) {
+    const int W = P.C / 64;
+    return A.queue_order && W <= 256 && ((B + 7) / 8) * W <= QB_THREADS * QB_TRIPS && !(P.dev & 16) && !(P.dev & (1024 | 2048));
+}
+
+// float64 search: persistent waves on the per-XCD queues, one 64-candidate unit at a time
+template <int CAND, bool HI, bool VALUE>
+static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A, hipStream_t st) {
+    const int W = P.C / 64;
+    if ((P.dev & 2048) && !VALUE && P.N <= LIT_MAX_N) {       // measurement variant: the literal wave-per-trajectory mapping
+        hipLaunchKernelGGL((search_literal_f64_kernel<CAND, HI>), dim3(B), dim3(64 * LIT_WAVES), 0, st, P, B, W, A.x0, A.u_prev,
+                           A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c);
+        return hipGetLastError();
+    }
+    const size_t total = (size_t)B * W;
+    // 2 waves per SIMD (232 VGPRs, no spill); the 3-per-SIMD build spills 244 B/lane and is 3-8 % behind at every batch
+    // size (IGT_DEV_FLAGS = 32 selects it for A/B runs)
+    const bool o3 = (P.dev & 32) != 0;
+    const size_t slots = (size_t)A.n_cu * 4 * (o3 ? 3 : 2);
+    const size_t grid = total < slots ? total : slots;
+    const unsigned* order = nullptr;
+    const int order_stride = ((B + 7) / 8) * W;
+    if (search_builds_queues(P, B, A)) {                     // small batches: longest units first
+        hipLaunchKernelGGL(build_queues_kernel<double>, dim3(8), dim3(QB_THREADS), 0, st, P, B, W, A.x0, A.kparams,
+                           A.queue_order, order_stride, A.work_counter);
+        order = A.queue_order;
+    }
+    if (o3)
+        hipLaunchKernelGGL((search_f64_kernel_o3<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter, order,
+                           order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c,
+                           A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b, A.unit_seg);
+    else {
+        // the reference's discretisation (4 sub-steps, short polynomials) has its own build of the kernel
+        constexpr int NRK4 = HI ? 0 : 4;
+        const bool rk4 = NRK4 == 4 && P.n_rk4 == 4;
+#define IGT_LAUNCH_S64(KERNEL, NRK_)                                                                                          \
+        hipLaunchKernelGGL((KERNEL<CAND, HI, VALUE, NRK_>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter, order,     \
+                           order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, \
+                           A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b, A.unit_seg)
+        if constexpr (CAND == CAND_TRACK) {
+            if (rk4) IGT_LAUNCH_S64(search_f64_kernel_o2w, NRK4); else IGT_LAUNCH_S64(search_f64_kernel_o2w, 0);
+        } else {
+            if (rk4) IGT_LAUNCH_S64(search_f64_kernel_o2, NRK4); else IGT_LAUNCH_S64(search_f64_kernel_o2, 0);
+        }
+#undef IGT_LAUNCH_S64
+    }
+    return hipGetLastError();
+}
+template <bool VALUE>
+static hipError_t dispatch_search64(const KP& P, int B, const SolveArgs<double>& A, hipStream_t st) {
+    if (P.dev & 1024) return launch_search_exact<VALUE>(P, B, A, st);     // developer switch: oracle-order kernels
+    if (P.hi_order) {
+        if (P.cand_mode == CAND_LATTICE) return launch_search64<CAND_LATTICE, true, VALUE>(P, B, A, st);
+        if (P.cand_mode == CAND_RAMP_HOLD) return launch_search64<CAND_RAMP_HOLD, true, VALUE>(P, B, A, st);
+        if (P.cand_mode == CAND_TRACK) return launch_search64<CAND_TRACK, true, VALUE>(P, B, A, st);
+        return launch_search64<CAND_TABLE, true, VALUE>(P, B, A, st);
+    }
+    if (P.cand_mode == CAND_LATTICE) return launch_search64<CAND_LATTICE, false, VALUE>(P, B, A, st);
+    if (P.cand_mode == CAND_RAMP_HOLD) return launch_search64<CAND_RAMP_HOLD, false, VALUE>(P, B, A, st);
+    if (P.cand_mode == CAND_TRACK) return launch_search64<CAND_TRACK, false, VALUE>(P, B, A, st);
+    return launch_search64<CAND_TABLE, false, VALUE>(P, B, A, st);
+}
+template <>
+hipError_t launch_search<double>(const KP& P, int B, const SolveArgs<double>& A, int, hipStream_t st) {
+    return dispatch_search64<false>(P, B, A, st);
+}
+template <>
+hipError_t launch_search_records<double>(const KP& P, int B, const SolveArgs<double>& A, hipStream_t st) {
+    return dispatch_search64<true>(P, B, A, st);
+}
+
+template <int CAND, bool HI>
+static hipError_t launch_emit64(const KP& P, int B, int W, const SolveArgs<double>& A, hipStream_t st) {
+    constexpr int NRK4 = HI ? 0 : 4;
+    if (NRK4 == 4 && P.n_rk4 == 4)
+        hipLaunchKernelGGL((emit_f64_kernel<CAND, HI, NRK4>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, W, A.x0, A.u_prev, A.kparams,
+                           A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, A.cost_out, A.argmin_out, A.status_out,
+                           A.x_out, A.u_out);
+    else
+        hipLaunchKernelGGL((emit_f64_kernel<CAND, HI, 0>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, W, A.x0, A.u_prev, A.kparams,
+                           A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, A.cost_out, A.argmin_out, A.status_out,
+                           A.x_out, A.u_out);
+    return hipGetLastError();
+}
+template <>
+hipError_t launch_emit<double>(const KP& P, int B, int W, const SolveArgs<double>& A, hipStream_t st) {
+    if (P.dev & 1024) {     // developer switch: oracle-order kernels (argmin_out is already final there)
+        hipLaunchKernelGGL((emit_kernel<ExactStepper<double>, double>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, A.x0,
+                           A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.argmin_out, A.x_out, A.u_out);
+        return hipGetLastError();
+    }
+    if (P.hi_order) {
+        if (P.cand_mode == CAND_LATTICE) return launch_emit64<CAND_LATTICE, true>(P, B, W, A, st);
+        if (P.cand_mode == CAND_RAMP_HOLD) return launch_emit64<CAND_RAMP_HOLD, true>(P, B, W, A, st);
+        if (P.cand_mode == CAND_TRACK) return launch_emit64<CAND_TRACK, true>(P, B, W, A, st);
+        return launch_emit64<CAND_TABLE, true>(P, B, W, A, st);
+    }
+    if (P.cand_mode == CAND_LATTICE) return launch_emit64<CAND_LATTICE, false>(P, B, W, A, st);
+    if (P.cand_mode == CAND_RAMP_HOLD) return launch_emit64<CAND_RAMP_HOLD, false>(P, B, W, A, st);
+    if (P.cand_mode == CAND_TRACK) return launch_emit64<CAND_TRACK, false>(P, B, W, A, st);
+    return launch_emit64<CAND_TABLE, false>(P, B, W, A, st);
+}
+
+template <int CAND, bool HI>
+static hipError_t launch_rollout_all64(const KP& P, int B, const SolveArgs<double>& A, double* X_all, double* U_all,
+                                       double* cost_all, uint32_t* viol_all, hipStream_t st) {
+    hipLaunchKernelGGL((rollout_all_f64_kernel<CAND, HI>), dim3((B + 3) / 4), dim3(256), 0, st, P, B, A.x0, A.u_prev,
+                       A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), X_all, U_all, cost_all, viol_all, A.rec_sN, A.rec_vN,
+                       A.rec_J, A.rec_viol);
+    return hipGetLastError();
+}
+template <>
+hipError_t launch_rollout_all<double>(const KP& P, int B, const SolveArgs<double>& A, double* X_all, double* U_all,
+                                      double* cost_all, uint32_t* viol_all, hipStream_t st) {
+    if (P.dev & 1024) {     // developer switch: oracle-order kernels
+        hipLaunchKernelGGL((rollout_all_kernel<ExactStepper<double>, double>), dim3((B + 3) / 4), dim3(256), 0, st, P, B,
+                           A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), X_all, U_all, cost_all, viol_all,
+                           A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
+        return hipGetLastError();
+    }
+    if (P.hi_order) {
+        if (P.cand_mode == CAND_LATTICE) return launch_rollout_all64<CAND_LATTICE, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+        if (P.cand_mode == CAND_RAMP_HOLD) return launch_rollout_all64<CAND_RAMP_HOLD, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+        if (P.cand_mode == CAND_TRACK) return launch_rollout_all64<CAND_TRACK, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+        return launch_rollout_all64<CAND_TABLE, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+    }
+    if (P.cand_mode == CAND_LATTICE) return launch_rollout_all64<CAND_LATTICE, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+    if (P.cand_mode == CAND_RAMP_HOLD) return launch_rollout_all64<CAND_RAMP_HOLD, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+    if (P.cand_mode == CAND_TRACK) return launch_rollout_all64<CAND_TRACK, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+    return launch_rollout_all64<CAND_TABLE, false>(P, B, A, X_all, U_all, cost_all, viol_all, st);
+}
+
+}  // namespace igt
