@@ -115,7 +115,8 @@ struct Fast64 {
 
     // MODE 0: general (K decided per stage argument); 1: K == 0 at every stage argument of every lane; 2: every stage
     // argument of every lane lies strictly inside the arc, K == kv.  All three give identical bits where they apply.
-    template <int MODE>
+    // XY = false (search units whose obstacles are out of every candidate's reach): the Cartesian rows are not integrated
+    template <int MODE, bool XY = true>
     __device__ __forceinline__ void substep(const StepConst& sc, Work& w) const {
         constexpr bool K0 = MODE == 1, KC = MODE == 2;
         const double ha = sc.ha, sblr = sc.sblr;
@@ -188,18 +189,20 @@ struct Fast64 {
         const double is = h6 * fma(c1, As, -(s1 * Bs));
         const double ie = h6 * fma(s1, Ae, c1 * Be);
         // ---- Cartesian rows collapse to one rotation of (A,B) as well (stage 4 shares stage 3's offset)
-        const double v34 = fma(2.0, v2, v4);
-        const double tv2 = 2.0 * v2;
-        const double Ac = fma(v34, cd3, fma(tv2, cd2, v1));
-        const double Bc = fma(v34, sd3, tv2 * sd2);
-        w.acc_x = fma(h6, fma(w.c2, Ac, -(w.s2 * Bc)), w.acc_x);
-        w.acc_y = fma(h6, fma(w.s2, Ac, w.c2 * Bc), w.acc_y);
+        if (XY) {
+            const double v34 = fma(2.0, v2, v4);
+            const double tv2 = 2.0 * v2;
+            const double Ac = fma(v34, cd3, fma(tv2, cd2, v1));
+            const double Bc = fma(v34, sd3, tv2 * sd2);
+            w.acc_x = fma(h6, fma(w.c2, Ac, -(w.s2 * Bc)), w.acc_x);
+            w.acc_y = fma(h6, fma(w.s2, Ac, w.c2 * Bc), w.acc_y);
+        }
         w.acc_psi = fma(h6, w1 + 4.0 * w2 + w4, w.acc_psi);
         w.acc_s += is; w.acc_ey += ie; w.acc_ep += ip;
         w.d0 += is; w.d1 += is; w.ey += ie; w.v1 = v4;
         // ---- base pairs for the next sub-step: (psi+beta) advances by h w2, (beta+epsi) by h w2 - corr: the psi
         // advance turned back by corr.  K == 0: corr = 0 exactly, the extra turn is by (0, 1) -- bit-identical variants.
-        rotate(w.s2, w.c2, sdP, cdP);
+        if (XY) rotate(w.s2, w.c2, sdP, cdP);
         rotate(w.s1, w.c1, sdP, cdP);
         if (!K0) {
             double sk, ck;
@@ -214,16 +217,16 @@ struct Fast64 {
     // the arc [b0, b1] by the travel bound |ds| <= 2 |v| (1/(1 - K ey) < 2 for any state near the road).
     // UNIFORM = false (emit: the lanes of a wave belong to different scenarios): the same choice by votes over the lanes.
     // the n_rk4 sub-steps of one variant; the reference's discretisation (4) is unrolled: no loop-carried register copies
-    template <int MODE>
+    template <int MODE, bool XY>
     __device__ __forceinline__ void run(const StepConst& sc, Work& w) const {
         if (NRK == 4 || (NRK == 0 && n_rk4 == 4)) {
-            substep<MODE>(sc, w); substep<MODE>(sc, w); substep<MODE>(sc, w); substep<MODE>(sc, w);
+            substep<MODE, XY>(sc, w); substep<MODE, XY>(sc, w); substep<MODE, XY>(sc, w); substep<MODE, XY>(sc, w);
         } else {
-            for (int j = 0; j < nrk(); ++j) substep<MODE>(sc, w);
+            for (int j = 0; j < nrk(); ++j) substep<MODE, XY>(sc, w);
         }
     }
 
-    template <bool UNIFORM>
+    template <bool UNIFORM, bool XY = true>
     __device__ __forceinline__ void substeps(double a, double sblr, Work& w) const {
         const double ha = hh * a;
         StepConst sc;
@@ -239,7 +242,7 @@ struct Fast64 {
         // scenario per lane) the whole-step decisions are taken by votes over the active lanes -- the variants are
         // bit-identical where they apply
         if (UNIFORM && kv == 0.0) {
-            run<1>(sc, w);
+            run<1, XY>(sc, w);
             return;
         }
         {   // the whole control step: |travel| <= 2 dt (|v| + dt |a|)   (a straight route's d0, d1 are -inf: clear)
@@ -247,16 +250,16 @@ struct Fast64 {
             const bool clear = (w.d0 + m < 0.0) | (w.d1 - m > 0.0);
             const bool inside = (w.d0 - m > 0.0) & (w.d1 + m < 0.0);
             if (__all(clear)) {
-                run<1>(sc, w);
+                run<1, XY>(sc, w);
                 return;
             }
             if (__all(inside)) {
-                run<2>(sc, w);
+                run<2, XY>(sc, w);
                 return;
             }
         }
         if (!UNIFORM) {                        // lanes of different scenarios rarely agree sub-step by sub-step
-            run<0>(sc, w);
+            run<0, XY>(sc, w);
             return;
         }
         for (int j = 0; j < nrk(); ++j) {
@@ -264,9 +267,9 @@ struct Fast64 {
             const double m = (2.0 * h) * (fabs(w.v1) + 2.0 * fabs(ha));
             const bool clear = (w.d0 + m < 0.0) | (w.d1 - m > 0.0);
             const bool inside = (w.d0 - m > 0.0) & (w.d1 + m < 0.0);
-            if (__all(clear)) substep<1>(sc, w);
-            else if (__all(inside)) substep<2>(sc, w);
-            else substep<0>(sc, w);
+            if (__all(clear)) substep<1, XY>(sc, w);
+            else if (__all(inside)) substep<2, XY>(sc, w);
+            else substep<0, XY>(sc, w);
         }
     }
 };
@@ -332,7 +335,27 @@ __device__ __forceinline__ void fill_steer_table(const KP& P, const Scenario<dou
     __syncthreads();
 }
 
-template <int CAND, bool HI_ORDER, bool BOOK, bool UNIFORM, class Sink, bool EARLY_EXIT = false, bool STAB = false, int NRK = 0>
+// Whether no candidate of the scenario that holds the speed box can come within d_min of any forecast position (wave-uniform;
+// the lanes share the horizon).  A control step moves the vehicle by at most dt max(|v_k|, |v_k+1|) (the RK4 stage speeds lie
+// between the two), speed-feasible candidates have |v_k| <= max(|v_min|, |v_max|) + tol for k < N, and |v_N| exceeds that by at
+// most max|a| dt: the reach over the horizon is N dt (v_abs + a_abs dt), taken with a metre to spare.  A candidate outside
+// the speed box is infeasible whatever its distance to the obstacle, so the search's answer is the same either way.
+__device__ __forceinline__ bool obstacles_out_of_reach(const KP& P, const Scenario<double>& S, int lane) {
+    const double reach = (fmax(fabs(P.v_min), fabs(P.v_max)) + fmax(fabs(P.a_min), fabs(P.a_max)) * P.dt) * (P.N * P.dt) + 1.0;
+    const double lim = sqrt(P.dmin2) + reach, lim2 = lim * lim;
+    bool near = false;
+    for (int e = lane; e < P.n_obs * P.N; e += 64) {
+        const int o = e / P.N, k = e - o * P.N + 1;
+        const double dx = S.x0[0] - S.obs[(o * 2 + 0) * (P.N + 1) + k], dy = S.x0[1] - S.obs[(o * 2 + 1) * (P.N + 1) + k];
+        near |= !(dx * dx + dy * dy > lim2);                      // NaN counts as near
+    }
+    return !__any(near);
+}
+
+// XY = false (search only, decided per unit by obstacles_out_of_reach): x, y are neither integrated nor judged -- no candidate
+// that holds the speed box can come within d_min of any forecast position, and one that does not is infeasible already.
+template <int CAND, bool HI_ORDER, bool BOOK, bool UNIFORM, class Sink, bool EARLY_EXIT = false, bool STAB = false, int NRK = 0,
+          bool XY = true>
 __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>& S, int cidx,
                                             const double* __restrict__ table, const double* __restrict__ cinf,
                                             Sink& sink, double& Jout, unsigned& vout, double& sN, double& vN,
@@ -363,7 +386,8 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
     sink.state(0, 0, S.x0);
     typename FP::Work w;
     w.d0 = w.d1 = 0.0;
-    sincos_reduced(S.x0[6], w.s2, w.c2);       // carried as (sin,cos)(psi + beta_k); beta_{-1} = 0
+    if (XY) sincos_reduced(S.x0[6], w.s2, w.c2);       // carried as (sin,cos)(psi + beta_k); beta_{-1} = 0
+    else { w.s2 = 0.0; w.c2 = 1.0; }
     // (sin,cos)(epsi + beta_k) is carried the same way: the sub-steps turn the pair by exactly the angle epsi advances by
     // (substep(): h w2 - corr per sub-step), so after control step k-1 it holds (sin,cos)(epsi_k + beta_{k-1}) and step k
     // turns it by beta_k - beta_{k-1} -- no sincos(epsi) per control step (39 of ~460 instructions on a straight route)
@@ -428,7 +452,7 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
             const bool lost = (viol != 0) | (LEAN && gmax > P.tol);
             if (__all(lost) && !(P.dev & 2)) { dead = true; break; }
         }
-        if (BOOK && k >= 1) {                                                        // collision, mpc.py:223-226
+        if (BOOK && XY && k >= 1) {                                                  // collision, mpc.py:223-226
             for (int o = 0; o < P.n_obs; ++o) {
                 const double dx = x - S.obs[(o * 2 + 0) * (P.N + 1) + k], dy = y - S.obs[(o * 2 + 1) * (P.N + 1) + k];
                 const double g = P.dmin2 - (dx * dx + dy * dy);
@@ -441,17 +465,20 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
         {
             const double sdb = fma(sb, cb_prev, -(cb * sb_prev));
             const double cdb = fma(cb, cb_prev, sb * sb_prev);
-            rotate(w.s2, w.c2, sdb, cdb);
             rotate(w.s1, w.c1, sdb, cdb);
-            const double r2 = fma(fma(w.s2, w.s2, w.c2 * w.c2), -0.5, 1.5);
             const double r1 = fma(fma(w.s1, w.s1, w.c1 * w.c1), -0.5, 1.5);
-            w.s2 *= r2; w.c2 *= r2;
             w.s1 *= r1; w.c1 *= r1;
+            if (XY) {
+                rotate(w.s2, w.c2, sdb, cdb);
+                const double r2 = fma(fma(w.s2, w.s2, w.c2 * w.c2), -0.5, 1.5);
+                w.s2 *= r2; w.c2 *= r2;
+            }
             cb_prev = cb; sb_prev = sb;
         }
         w.acc_s = 0.0; w.acc_ey = 0.0; w.acc_ep = 0.0; w.acc_x = 0.0; w.acc_y = 0.0; w.acc_psi = 0.0;
-        fp.template substeps<UNIFORM>(a, sblr, w);
-        s += w.acc_s; ey += w.acc_ey; ep += w.acc_ep; x += w.acc_x; y += w.acc_y;
+        fp.template substeps<UNIFORM, XY>(a, sblr, w);
+        s += w.acc_s; ey += w.acc_ey; ep += w.acc_ep;
+        if (XY) { x += w.acc_x; y += w.acc_y; }
         if (KEEP_PSI) psi += w.acc_psi;        // psi feeds nothing back (search: dead code)
         v = fma(fp.dt, a, v);
         const double nxt[7] = {x, y, s, ey, ep, v, psi};
@@ -466,7 +493,7 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
         J = J + ey * ey;
         if (LEAN) gmax = fmax(gmax, fabs(ey) - P.ey_lim);
         else if (fabs(ey) - P.ey_lim > P.tol) viol |= VIOL_EY;
-        for (int o = 0; o < P.n_obs; ++o) {
+        for (int o = 0; XY && o < P.n_obs; ++o) {
             const double dx = x - S.obs[(o * 2 + 0) * (P.N + 1) + P.N], dy = y - S.obs[(o * 2 + 1) * (P.N + 1) + P.N];
             const double g = P.dmin2 - (dx * dx + dy * dy);
             if (LEAN) gmax = fmax(gmax, g);
