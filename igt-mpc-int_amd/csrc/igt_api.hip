@@ -321,7 +321,7 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     {
         const size_t n_rec = value ? (size_t)B * p.C : 0;
         const size_t need = (size_t)B * W * 12 + (size_t)B * 56 + 8192 + ckpt_bytes + (size_t)(B + 8) * Wk * 36 + 256 + n_rec * (2 * sizeof(T) + 16) +
-                            (value ? (size_t)B * igt::VN_H * sizeof(T) + (size_t)B * Wk * 8 : 0) + 20 * 256;
+                            (value ? (size_t)B * igt::VN_H * sizeof(T) + (size_t)B * Wk * 8 + (size_t)B * 8 + n_rec * 4 + 512 : 0) + 20 * 256;
         if (int rc = ensure_work(h, need, st)) return rc;
         Arena wa{(char*)h->d_work, 0};
         A.part_J = wa.take<double>((size_t)B * W);
@@ -346,6 +346,10 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
             A.rec_count = wa.take<unsigned>(64);
             A.best_key = wa.take<unsigned long long>((size_t)B);
             A.unit_seg = wa.take<int2>((size_t)B * Wk);
+            if (sizeof(T) == 8) {
+                A.prune_thr = wa.take<double>((size_t)B);
+                A.live_idx = wa.take<unsigned>(n_rec);
+            }
         }
     }
     if (h->prof) HIPCHK(hipEventRecord(h->ev[0], st));

@@ -639,15 +639,29 @@ hipError_t launch_value<double>(const KP& P, int B, const DevNet<double>& net, c
                                 double* cost_all, uint32_t* viol_all, hipStream_t st) {
     if (!cost_all && !(P.dev & 1024)) {   // solve path: the compact list of feasible candidates on the f64 matrix cores
         const size_t lds = (size_t)FRAGD_LDS * sizeof(double);
+        const int n_units = B * (P.C / 64);
+        // prune the list first (value_bound_kernel): scenarios with many feasible candidates -- the tracking and ramp-hold
+        // families -- keep a fraction of their entries; short lists (the lattice's 14 per scenario) are left alone
+        const bool prune = A.live_idx && !(P.dev & 131072);
+        // ... when the list averages at least 32 entries per scenario (decided on the device from the list's length; the
+        // surviving entries are counted in rec_count[16], zeroed with rec_count[0] before the search)
+        const unsigned prune_min = (unsigned)B * 32u;
+        if (prune) {
+            hipLaunchKernelGGL(value_bound_kernel, dim3(B), dim3(64), 0, st, B, P.C / 64, 48, net.n_hidden_mats, net, A.rec_count,
+                               prune_min, A.unit_seg, A.rec_sN, A.rec_vN, A.rec_J, A.tv_sv, A.enc, A.prune_thr);
+            hipLaunchKernelGGL(value_prune_kernel, dim3(A.n_cu * 4), dim3(256), 0, st, A.rec_count, prune_min, A.rec_b, A.rec_J,
+                               A.prune_thr, A.live_idx);
+            hipError_t e0 = hipGetLastError();
+            if (e0 != hipSuccess) return e0;
+        }
         if (net.n_hidden_mats > 1)
-            hipLaunchKernelGGL(value_mfma_f64_kernel<2>, dim3(A.n_cu), dim3(512), lds, st, net, A.rec_count, A.rec_b, A.rec_sN,
-                               A.rec_vN, A.rec_J, A.tv_sv, A.enc);
+            hipLaunchKernelGGL(value_mfma_f64_kernel<2>, dim3(A.n_cu), dim3(512), lds, st, net, A.rec_count,
+                               prune ? A.live_idx : nullptr, prune_min, A.rec_b, A.rec_sN, A.rec_vN, A.rec_J, A.tv_sv, A.enc);
         else
-            hipLaunchKernelGGL(value_mfma_f64_kernel<1>, dim3(A.n_cu), dim3(512), lds, st, net, A.rec_count, A.rec_b, A.rec_sN,
-                               A.rec_vN, A.rec_J, A.tv_sv, A.enc);
+            hipLaunchKernelGGL(value_mfma_f64_kernel<1>, dim3(A.n_cu), dim3(512), lds, st, net, A.rec_count,
+                               prune ? A.live_idx : nullptr, prune_min, A.rec_b, A.rec_sN, A.rec_vN, A.rec_J, A.tv_sv, A.enc);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        const int n_units = B * (P.C / 64);
         hipLaunchKernelGGL(unit_reduce_kernel, dim3((n_units + 255) / 256), dim3(256), 0, st, n_units, A.unit_seg, A.rec_J,
                            reinterpret_cast<const int32_t*>(A.rec_viol), A.part_J, A.part_c);
         return hipGetLastError();

@@ -44,6 +44,8 @@ struct SolveArgs {   // all device pointers
     int32_t* rec_b;
     unsigned long long* best_key;   // [B] per-scenario (orderable cost, candidate) minimum
     int2* unit_seg;                 // double path: [B, C/64] (first entry, count) of each unit's entries in the compact list
+    double* prune_thr;              // double path: [B] cost above which an entry cannot win (value_bound_kernel)
+    unsigned* live_idx;             // double path: entries left for the network after value_prune_kernel
 };
 
 bool search_builds_queues(const KP& P, int B, const SolveArgs<float>& A);   // then no memset of the counters is needed

@@ -454,8 +454,12 @@ __device__ __forceinline__ double tanh_d(double x) {
 constexpr int FRAGD_LDS_SMALL = FRAGD_A1 + 2 * FRAGD_B + FRAGD_B;      // A1F | BF[0..1] | WOF
 constexpr int FRAGD_LDS = FRAGD_W + FRAGD_LDS_SMALL;                   // doubles (139 KB)
 
+// live_idx (optional): the entries still to be evaluated after value_prune_kernel -- used when the list was long enough to
+// be pruned (rec_count[0] >= prune_min, the predicate value_bound_kernel and value_prune_kernel evaluate too; their count
+// is rec_count[16]); otherwise every entry of the list.
 template <int NM>
 __global__ __launch_bounds__(512) void value_mfma_f64_kernel(DevNet<double> net, const unsigned* __restrict__ rec_count,
+                                                             const unsigned* __restrict__ live_idx_, unsigned prune_min,
                                                              const int32_t* __restrict__ rec_b,
                                                              const double* __restrict__ rec_sN,
                                                              const double* __restrict__ rec_vN, double* __restrict__ rec_J,
@@ -471,11 +475,14 @@ __global__ __launch_bounds__(512) void value_mfma_f64_kernel(DevNet<double> net,
     for (int i = threadIdx.x; i < FRAGD_B; i += 512) WOF[i] = WFg[NM * FRAGD_W + NM * FRAGD_B + i];
     __syncthreads();
     const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
-    const unsigned count = *rec_count;
+    const bool pruned = live_idx_ && rec_count[0] >= prune_min;
+    const unsigned* __restrict__ live_idx = pruned ? live_idx_ : nullptr;
+    const unsigned count = pruned ? rec_count[16] : rec_count[0];
     const unsigned wave = blockIdx.x * 8u + (threadIdx.x >> 6), nwaves = gridDim.x * 8u;
     for (unsigned base = wave * 16u; base < count; base += nwaves * 16u) {
-        const unsigned e = base + (unsigned)col;
-        const bool live = e < count;
+        const unsigned slot = base + (unsigned)col;
+        const bool live = slot < count;
+        const unsigned e = live ? (live_idx ? live_idx[slot] : slot) : 0u;
         const int b = live ? rec_b[e] : 0;
         const double sN = live ? rec_sN[e] : 0.0, vN = live ? rec_vN[e] : 0.0;
         const double s_tv = tv_sv[(size_t)b * 2 + 0], v_tv = tv_sv[(size_t)b * 2 + 1];
@@ -551,6 +558,137 @@ __global__ __launch_bounds__(512) void value_mfma_f64_kernel(DevNet<double> net,
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
         if (live && g == 0) rec_J[e] = rec_J[e] - ((v + net.bout) * net.sigma_t + net.mu_t);      // mpc.py:369
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Pruning the compact list before the network runs (double path).  The cost of an entry is J_e - V(x_e) (mpc.py:369) and
+// the hidden layers are tanh, so V is bounded on any box of features.  Per scenario -- only s_N and v_N differ between its
+// entries -- one wave
+//   * takes the box [s_N] x [v_N] of the scenario's entries and the entry a with the smallest J,
+//   * pushes the box through the network as centre / radius intervals (affine layers: c' = W c + b, r' = |W| r; tanh is
+//     monotone: [tanh(c - r), tanh(c + r)]) -> V <= V_hi on the box, and evaluates V(x_a) exactly,
+//   * writes thr[b] = (J_a - V(x_a)) + V_hi: an entry with J_e > thr[b] costs more than entry a whatever its V, it cannot
+//     be the arg-min.  value_prune_kernel drops those (their cost becomes +inf, which unit_reduce_kernel skips) and
+//     lists the others for value_mfma_f64_kernel.
+// Nothing is approximated: the surviving entries get the same costs as without pruning, the winner is the same entry.
+// Measured on the benchmark batch (tools/prune_probe.py, identity normalisation): 16 % of the tracking family's list
+// survives with V_GT_sc1, 39 % with V_GT_sc3.  The bound costs about as much as 16 entries of a scenario, so it is taken
+// only where lists are long: the whole step is skipped -- by all three kernels, on the same predicate -- when the list holds
+// fewer than prune_min entries (the lattice's 14 per scenario), and a scenario with fewer than min_entries gets thr = +inf.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void value_bound_kernel(int B, int W, int min_entries, int nm, DevNet<double> net,
+                                                         const unsigned* __restrict__ rec_count, unsigned prune_min,
+                                                         const int2* __restrict__ unit_seg,
+                                                         const double* __restrict__ rec_sN,
+                                                         const double* __restrict__ rec_vN,
+                                                         const double* __restrict__ rec_J,
+                                                         const double* __restrict__ tv_sv, const double* __restrict__ enc,
+                                                         double* __restrict__ thr) {
+    __shared__ double hc[2][VN_H], hr[2][VN_H], ha[2][VN_H];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= B || rec_count[0] < prune_min) return;
+    int n_total = 0;
+    for (int p = 0; p < W; ++p) n_total += unit_seg[(size_t)b * W + p].y;
+    if (n_total < min_entries) {                       // wave-uniform
+        if (lane == 0) thr[b] = (double)INFINITY;
+        return;
+    }
+    double smin = 1e300, smax = -1e300, vmin = 1e300, vmax = -1e300, Ja = 1e300, sa = 0.0, va = 0.0;
+    for (int p = 0; p < W; ++p) {
+        const int2 sg = unit_seg[(size_t)b * W + p];
+        for (int e = sg.x + lane; e < sg.x + sg.y; e += 64) {
+            const double s = rec_sN[e], v = rec_vN[e], J = rec_J[e];
+            smin = fmin(smin, s); smax = fmax(smax, s); vmin = fmin(vmin, v); vmax = fmax(vmax, v);
+            if (J < Ja) { Ja = J; sa = s; va = v; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        smin = fmin(smin, __shfl_xor(smin, off, 64)); smax = fmax(smax, __shfl_xor(smax, off, 64));
+        vmin = fmin(vmin, __shfl_xor(vmin, off, 64)); vmax = fmax(vmax, __shfl_xor(vmax, off, 64));
+        const double oJ = __shfl_xor(Ja, off, 64), os = __shfl_xor(sa, off, 64), ov = __shfl_xor(va, off, 64);
+        // any entry with the smallest J will do as the anchor; ties are broken on (s, v) only to keep the lanes in agreement
+        if (oJ < Ja || (oJ == Ja && (os < sa || (os == sa && ov < va)))) { Ja = oJ; sa = os; va = ov; }
+    }
+    const double s_tv = tv_sv[(size_t)b * 2 + 0], v_tv = tv_sv[(size_t)b * 2 + 1];
+    const double e_ego = enc[(size_t)b * 2 + 0], e_tv = enc[(size_t)b * 2 + 1];
+    const double f0[6] = {s_tv, v_tv, e_tv, -s_tv, -v_tv, e_ego - e_tv};
+    const double sc = 0.5 * (smin + smax), sr = 0.5 * (smax - smin) * (1.0 + 1e-12) + 1e-300;
+    const double vc = 0.5 * (vmin + vmax), vr = 0.5 * (vmax - vmin) * (1.0 + 1e-12) + 1e-300;
+    constexpr double TANH_EPS = 1e-15;                 // tanh_d's absolute error, with room
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                      // layer 1: affine in (s_N, v_N)   (value_prep_kernel's p, q, r)
+        const int i = lane + 64 * q;
+        double p = net.c1[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p = fma(net.A1[i * 6 + k], f0[k], p);
+        const double qi = net.A1[i * 6 + 3], ri = net.A1[i * 6 + 4];
+        const double c = fma(ri, vc, fma(qi, sc, p)), r = fma(fabs(ri), vr, fabs(qi) * sr) + 1e-13 * (1.0 + fabs(c));
+        const double lo = tanh_d(c - r) - TANH_EPS, hi = tanh_d(c + r) + TANH_EPS;
+        hc[0][i] = 0.5 * (lo + hi); hr[0][i] = 0.5 * (hi - lo);
+        ha[0][i] = tanh_d(fma(ri, va, fma(qi, sa, p)));
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int m = 0; m < nm; ++m) {
+        const double* __restrict__ WT = net.WT[m];
+        double c0 = net.bias[m][lane], c1 = net.bias[m][lane + 64], r0 = 0.0, r1 = 0.0, a0 = c0, a1 = c1;
+        for (int i = 0; i < VN_H; ++i) {
+            const double w0 = WT[(size_t)i * VN_H + lane], w1 = WT[(size_t)i * VN_H + lane + 64];
+            const double xc = hc[cur][i], xr = hr[cur][i], xa = ha[cur][i];
+            c0 = fma(w0, xc, c0); r0 = fma(fabs(w0), xr, r0); a0 = fma(w0, xa, a0);
+            c1 = fma(w1, xc, c1); r1 = fma(fabs(w1), xr, r1); a1 = fma(w1, xa, a1);
+        }
+        r0 += 1e-13 * (1.0 + fabs(c0)); r1 += 1e-13 * (1.0 + fabs(c1));      // rounding of the 128-term sums, with room
+        const double l0 = tanh_d(c0 - r0) - TANH_EPS, h0 = tanh_d(c0 + r0) + TANH_EPS;
+        const double l1 = tanh_d(c1 - r1) - TANH_EPS, h1 = tanh_d(c1 + r1) + TANH_EPS;
+        hc[cur ^ 1][lane] = 0.5 * (l0 + h0); hr[cur ^ 1][lane] = 0.5 * (h0 - l0); ha[cur ^ 1][lane] = tanh_d(a0);
+        hc[cur ^ 1][lane + 64] = 0.5 * (l1 + h1); hr[cur ^ 1][lane + 64] = 0.5 * (h1 - l1); ha[cur ^ 1][lane + 64] = tanh_d(a1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    double cV = 0.0, rV = 0.0, aV = 0.0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int j = lane + 64 * q;
+        const double w = net.wout[j];
+        cV = fma(w, hc[cur][j], cV); rV = fma(fabs(w), hr[cur][j], rV); aV = fma(w, ha[cur][j], aV);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        cV += __shfl_xor(cV, off, 64); rV += __shfl_xor(rV, off, 64); aV += __shfl_xor(aV, off, 64);
+    }
+    if (lane == 0) {
+        // scaled value (mpc.py:369): V sigma_t + mu_t; upper end of the interval whatever the sign of sigma_t
+        const double v_hi = fma(cV + net.bout, net.sigma_t, net.mu_t) + fabs(net.sigma_t) * rV;
+        const double v_a = fma(aV + net.bout, net.sigma_t, net.mu_t);
+        const double t = (Ja - v_a) + v_hi;
+        thr[b] = t + 1e-9 * (1.0 + fabs(Ja) + fabs(v_a) + fabs(v_hi));     // evaluation order differs from the MFMA kernel's
+    }
+}
+
+// entries with J_e > thr[b_e] cannot win: cost +inf; the others are listed (in any order) for value_mfma_f64_kernel
+__global__ __launch_bounds__(256) void value_prune_kernel(unsigned* __restrict__ rec_count, unsigned prune_min,
+                                                          const int32_t* __restrict__ rec_b, double* __restrict__ rec_J,
+                                                          const double* __restrict__ thr, unsigned* __restrict__ live_idx) {
+    const unsigned count = rec_count[0], lane = threadIdx.x & 63u;
+    if (count < prune_min) return;
+    unsigned* live_count = rec_count + 16;
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned e0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); e0 < count; e0 += stride) {   // whole waves
+        const unsigned e = e0 + lane;
+        bool keep = false;
+        if (e < count) {
+            keep = rec_J[e] <= thr[rec_b[e]];
+            if (!keep) rec_J[e] = (double)INFINITY;
+        }
+        const unsigned long long m = __ballot(keep);
+        const unsigned n = __popcll(m);
+        unsigned base = 0;
+        if (lane == 0 && n) base = atomicAdd(live_count, n);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (keep) live_idx[base + __popcll(m & ((1ull << lane) - 1ull))] = e;
     }
 }
 

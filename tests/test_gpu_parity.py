@@ -534,6 +534,46 @@ def test_value_net_with_ramp_hold_refinement_f64(igt, golden_dir):
     assert rel_err(got['cost'][sol], ref['cost'][sol]).max() < 1e-9
 
 
+@pytest.mark.parametrize('sc', [1, 3])
+def test_value_bound_pruning_changes_nothing(igt, golden_dir, sc, monkeypatch):
+    """gt_mpc cost, tracking candidates (long lists of feasible candidates): the list is pruned with an interval bound on
+    the value network before the matrix-core kernel runs (value_bound_kernel / value_prune_kernel).  Entries that are dropped
+    cannot win, so the solve with pruning == the solve without (IGT_DEV_FLAGS = 131072), bit for bit -- with a non-trivial
+    whitening and a NEGATIVE sigma_t as well (the bound takes the upper end whatever the sign)."""
+    layers = _nets(golden_dir)[sc]
+    rng = np.random.default_rng(9)
+    nets = [dict(layers=layers, Wn=np.eye(6), mu_f=np.zeros(6), sigma_t=1.0, mu_t=0.0),
+            dict(layers=layers, Wn=np.eye(6) + 0.05 * rng.normal(size=(6, 6)),
+                 mu_f=np.array([20.0, 2.5, 0.0, 0.0, 0.0, 0.0]), sigma_t=-2.0, mu_t=0.7)]
+    b = _batch(768, np.float64)
+    for net in nets:
+        outs = []
+        for flag in ('0', '131072'):
+            monkeypatch.setenv('IGT_DEV_FLAGS', flag)
+            with igt.BatchSolver(dtype='f64', cost_mode='value_net', cand_mode='track') as s:
+                s.set_cinf(*_cinf())
+                s.set_value_net(**net)
+                outs.append(s.solve(*_args(b), b['tv_sv'], b['enc']))
+        monkeypatch.delenv('IGT_DEV_FLAGS')
+        assert (outs[0]['status'] == 0).mean() > 0.5
+        for k in ('x', 'u', 'cost', 'argmin', 'status'):
+            assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+    # ... and the pruned solve is the oracle's answer (one scenario subset, sigma_t = 1)
+    P = O.Params(N=20)
+    f = lambda k: np.asarray(b[k][:64], dtype=np.float64)
+    ref = O.solve_batch_refined(f('x0'), f('u_prev'), f('kparams'), b['flags'][:64], f('obs_xy'), *_cinf(), P, cand='track',
+                                net=nets[0], tv_sv=f('tv_sv'), enc=f('enc'))[0]
+    with igt.BatchSolver(dtype='f64', cost_mode='value_net', cand_mode='track') as s:
+        s.set_cinf(*_cinf())
+        s.set_value_net(**nets[0])
+        got = s.solve(*[a[:64] for a in _args(b)], b['tv_sv'][:64], b['enc'][:64])
+    amb = ambiguous_mask(ref, P, 1e-9, 1e-9)
+    ok = ~amb
+    assert ok.mean() > 0.8 and (got['argmin'][ok] == ref['argmin'][ok]).all()
+    sol = ok & (ref['status'] == 0)
+    assert rel_err(got['cost'][sol], ref['cost'][sol]).max() < 1e-9
+
+
 # ----------------------------------------------------------------------------- warm start (augment_prev_sol)
 @pytest.mark.parametrize('dtype,tol,eps', [('f64', 1e-9, 1e-9), ('f32', REL_TOL, 2e-5)])
 def test_warm_started_ramp_hold_matches_oracle(igt, dtype, tol, eps):
