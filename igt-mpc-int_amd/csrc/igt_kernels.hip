@@ -642,24 +642,22 @@ hipError_t launch_value<double>(const KP& P, int B, const DevNet<double>& net, c
         const int n_units = B * (P.C / 64);
         // prune the list first (value_bound_kernel): scenarios with many feasible candidates -- the tracking and ramp-hold
         // families -- keep a fraction of their entries; short lists (the lattice's 14 per scenario) are left alone
-        const bool prune = A.live_idx && !(P.dev & 131072);
-        // ... when the list averages at least 32 entries per scenario (decided on the device from the list's length; the
-        // surviving entries are counted in rec_count[16], zeroed with rec_count[0] before the search)
-        const unsigned prune_min = (unsigned)B * 32u;
-        if (prune) {
-            hipLaunchKernelGGL(value_bound_kernel, dim3(B), dim3(64), 0, st, B, P.C / 64, 48, net.n_hidden_mats, net, A.rec_count,
-                               prune_min, A.unit_seg, A.rec_sN, A.rec_vN, A.rec_J, A.tv_sv, A.enc, A.prune_thr);
-            hipLaunchKernelGGL(value_prune_kernel, dim3(A.n_cu * 4), dim3(256), 0, st, A.rec_count, prune_min, A.rec_b, A.rec_J,
-                               A.prune_thr, A.live_idx);
-            hipError_t e0 = hipGetLastError();
-            if (e0 != hipSuccess) return e0;
-        }
+        // value_bound_kernel: scenarios with many feasible candidates -- the tracking and ramp-hold families -- keep a fraction
+        // of their entries; short lists (the lattice's 14 per scenario) are left alone.  IGT_DEV_FLAGS = 131072: no pruning.
+        const int min_entries = (P.dev & 131072) ? 0x7fffffff : 48;
+        unsigned* live_count = A.rec_count + 16;          // zeroed with rec_count before the search
+        hipLaunchKernelGGL(value_bound_kernel, dim3(B), dim3(64), 0, st, B, P.C / 64, min_entries, net.n_hidden_mats, net, A.unit_seg,
+                           A.rec_sN, A.rec_vN, A.rec_J, A.tv_sv, A.enc, A.prune_thr);
+        hipLaunchKernelGGL(value_select_kernel, dim3(A.n_cu * 4), dim3(256), 0, st, n_units, P.C / 64, A.unit_seg, A.rec_J,
+                           A.prune_thr, live_count, A.live_idx);
+        hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) return e0;
         if (net.n_hidden_mats > 1)
-            hipLaunchKernelGGL(value_mfma_f64_kernel<2>, dim3(A.n_cu), dim3(512), lds, st, net, A.rec_count,
-                               prune ? A.live_idx : nullptr, prune_min, A.rec_b, A.rec_sN, A.rec_vN, A.rec_J, A.tv_sv, A.enc);
+            hipLaunchKernelGGL(value_mfma_f64_kernel<2>, dim3(A.n_cu), dim3(512), lds, st, net, live_count, A.live_idx, A.rec_b,
+                               A.rec_sN, A.rec_vN, A.rec_J, A.tv_sv, A.enc);
         else
-            hipLaunchKernelGGL(value_mfma_f64_kernel<1>, dim3(A.n_cu), dim3(512), lds, st, net, A.rec_count,
-                               prune ? A.live_idx : nullptr, prune_min, A.rec_b, A.rec_sN, A.rec_vN, A.rec_J, A.tv_sv, A.enc);
+            hipLaunchKernelGGL(value_mfma_f64_kernel<1>, dim3(A.n_cu), dim3(512), lds, st, net, live_count, A.live_idx, A.rec_b,
+                               A.rec_sN, A.rec_vN, A.rec_J, A.tv_sv, A.enc);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(unit_reduce_kernel, dim3((n_units + 255) / 256), dim3(256), 0, st, n_units, A.unit_seg, A.rec_J,

@@ -211,12 +211,13 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
     }
     if (VALUE) {   // terminal value network (mpc.py:369): append the feasible candidates for value_mfma_f64_kernel; the
                    // unit's entries are contiguous, unit_seg remembers where (unit_reduce_kernel picks the unit's best)
+        // The unit's entries go to the unit's own 64 slots: no counter is shared between the units (a returning atomicAdd on
+        // one address retires every 11.4 ns on this part -- 262 144 units at B = 65 536 would queue for 3 ms); the dense list
+        // the network runs over is built afterwards from the units' counts (value_select_kernel).
         const bool ok = viol == 0 && finite_d(J);
         const unsigned long long m = __ballot(ok);
         const unsigned n = __popcll(m);
-        unsigned base = 0;
-        if (lane == 0 && n) base = atomicAdd(rec_count, n);
-        base = __builtin_amdgcn_readfirstlane(base);
+        const unsigned base = (unsigned)(b * W + p) * 64u;
         if (ok) {
             const unsigned e = base + __popcll(m & ((1ull << lane) - 1ull));
             rec_b[e] = b; reinterpret_cast<int32_t*>(rec_viol)[e] = c; rec_sN[e] = sN; rec_vN[e] = vN; rec_J[e] = J;

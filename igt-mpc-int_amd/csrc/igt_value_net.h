@@ -454,12 +454,10 @@ __device__ __forceinline__ double tanh_d(double x) {
 constexpr int FRAGD_LDS_SMALL = FRAGD_A1 + 2 * FRAGD_B + FRAGD_B;      // A1F | BF[0..1] | WOF
 constexpr int FRAGD_LDS = FRAGD_W + FRAGD_LDS_SMALL;                   // doubles (139 KB)
 
-// live_idx (optional): the entries still to be evaluated after value_prune_kernel -- used when the list was long enough to
-// be pruned (rec_count[0] >= prune_min, the predicate value_bound_kernel and value_prune_kernel evaluate too; their count
-// is rec_count[16]); otherwise every entry of the list.
+// live_idx[0 .. *live_count): the entries to evaluate (value_select_kernel); the entries themselves sit in their units' slots.
 template <int NM>
-__global__ __launch_bounds__(512) void value_mfma_f64_kernel(DevNet<double> net, const unsigned* __restrict__ rec_count,
-                                                             const unsigned* __restrict__ live_idx_, unsigned prune_min,
+__global__ __launch_bounds__(512) void value_mfma_f64_kernel(DevNet<double> net, const unsigned* __restrict__ live_count,
+                                                             const unsigned* __restrict__ live_idx,
                                                              const int32_t* __restrict__ rec_b,
                                                              const double* __restrict__ rec_sN,
                                                              const double* __restrict__ rec_vN, double* __restrict__ rec_J,
@@ -475,14 +473,12 @@ __global__ __launch_bounds__(512) void value_mfma_f64_kernel(DevNet<double> net,
     for (int i = threadIdx.x; i < FRAGD_B; i += 512) WOF[i] = WFg[NM * FRAGD_W + NM * FRAGD_B + i];
     __syncthreads();
     const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
-    const bool pruned = live_idx_ && rec_count[0] >= prune_min;
-    const unsigned* __restrict__ live_idx = pruned ? live_idx_ : nullptr;
-    const unsigned count = pruned ? rec_count[16] : rec_count[0];
+    const unsigned count = *live_count;
     const unsigned wave = blockIdx.x * 8u + (threadIdx.x >> 6), nwaves = gridDim.x * 8u;
     for (unsigned base = wave * 16u; base < count; base += nwaves * 16u) {
         const unsigned slot = base + (unsigned)col;
         const bool live = slot < count;
-        const unsigned e = live ? (live_idx ? live_idx[slot] : slot) : 0u;
+        const unsigned e = live ? live_idx[slot] : 0u;
         const int b = live ? rec_b[e] : 0;
         const double sN = live ? rec_sN[e] : 0.0, vN = live ? rec_vN[e] : 0.0;
         const double s_tv = tv_sv[(size_t)b * 2 + 0], v_tv = tv_sv[(size_t)b * 2 + 1];
@@ -573,12 +569,10 @@ __global__ __launch_bounds__(512) void value_mfma_f64_kernel(DevNet<double> net,
 //     lists the others for value_mfma_f64_kernel.
 // Nothing is approximated: the surviving entries get the same costs as without pruning, the winner is the same entry.
 // Measured on the benchmark batch (tools/prune_probe.py, identity normalisation): 16 % of the tracking family's list
-// survives with V_GT_sc1, 39 % with V_GT_sc3.  The bound costs about as much as 16 entries of a scenario, so it is taken
-// only where lists are long: the whole step is skipped -- by all three kernels, on the same predicate -- when the list holds
-// fewer than prune_min entries (the lattice's 14 per scenario), and a scenario with fewer than min_entries gets thr = +inf.
+// survives with V_GT_sc1, 39 % with V_GT_sc3.  The bound costs about as much as 16 entries of a scenario, so a scenario
+// with fewer than min_entries entries (the lattice's 14 on average) gets thr = +inf and keeps them all.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void value_bound_kernel(int B, int W, int min_entries, int nm, DevNet<double> net,
-                                                         const unsigned* __restrict__ rec_count, unsigned prune_min,
                                                          const int2* __restrict__ unit_seg,
                                                          const double* __restrict__ rec_sN,
                                                          const double* __restrict__ rec_vN,
@@ -587,7 +581,7 @@ __global__ __launch_bounds__(64) void value_bound_kernel(int B, int W, int min_e
                                                          double* __restrict__ thr) {
     __shared__ double hc[2][VN_H], hr[2][VN_H], ha[2][VN_H];
     const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= B || rec_count[0] < prune_min) return;
+    if (b >= B) return;
     int n_total = 0;
     for (int p = 0; p < W; ++p) n_total += unit_seg[(size_t)b * W + p].y;
     if (n_total < min_entries) {                       // wave-uniform
@@ -668,27 +662,44 @@ __global__ __launch_bounds__(64) void value_bound_kernel(int B, int W, int min_e
     }
 }
 
-// entries with J_e > thr[b_e] cannot win: cost +inf; the others are listed (in any order) for value_mfma_f64_kernel
-__global__ __launch_bounds__(256) void value_prune_kernel(unsigned* __restrict__ rec_count, unsigned prune_min,
-                                                          const int32_t* __restrict__ rec_b, double* __restrict__ rec_J,
-                                                          const double* __restrict__ thr, unsigned* __restrict__ live_idx) {
-    const unsigned count = rec_count[0], lane = threadIdx.x & 63u;
-    if (count < prune_min) return;
-    unsigned* live_count = rec_count + 16;
-    const unsigned stride = gridDim.x * blockDim.x;
-    for (unsigned e0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); e0 < count; e0 += stride) {   // whole waves
-        const unsigned e = e0 + lane;
-        bool keep = false;
-        if (e < count) {
-            keep = rec_J[e] <= thr[rec_b[e]];
-            if (!keep) rec_J[e] = (double)INFINITY;
+// The dense list the network runs over: every unit's entries with J_e <= thr[b] (the others cannot win: their cost becomes
+// +inf), in any order.  Each wave owns a contiguous range of units, counts its keeps, reserves its share of live_idx with ONE
+// atomicAdd and fills it -- a few thousand atomics per launch instead of one per unit.
+__global__ __launch_bounds__(256) void value_select_kernel(int n_units, int W, const int2* __restrict__ unit_seg,
+                                                           double* __restrict__ rec_J, const double* __restrict__ thr,
+                                                           unsigned* __restrict__ live_count, unsigned* __restrict__ live_idx) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = gridDim.x * (blockDim.x >> 6);
+    const int per = (n_units + nwaves - 1) / nwaves;
+    const int u0 = wave * per, u1 = (u0 + per < n_units) ? u0 + per : n_units;
+    // 64 units at a time: lane j loads unit j's segment and threshold (one coalesced load each), the wave then walks the
+    // units with the segment broadcast from lane j; lane j keeps unit j's keep-mask for the second pass
+    for (int t0 = u0; t0 < u1; t0 += 64) {
+        const int nu = (u1 - t0 < 64) ? u1 - t0 : 64;
+        const int2 mine = lane < nu ? unit_seg[t0 + lane] : make_int2(0, 0);
+        const double my_thr = lane < nu ? thr[(t0 + lane) / W] : 0.0;
+        unsigned long long my_mask = 0ull;
+        unsigned total = 0;
+#pragma unroll 4
+        for (int j = 0; j < nu; ++j) {
+            const int base = __shfl(mine.x, j, 64), n = __shfl(mine.y, j, 64);
+            const double tj = __shfl(my_thr, j, 64);
+            const bool keep = lane < n && rec_J[base + lane] <= tj;
+            const unsigned long long m = __ballot(keep);
+            if (lane == j) my_mask = m;
+            total += (unsigned)__popcll(m);
         }
-        const unsigned long long m = __ballot(keep);
-        const unsigned n = __popcll(m);
-        unsigned base = 0;
-        if (lane == 0 && n) base = atomicAdd(live_count, n);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (keep) live_idx[base + __popcll(m & ((1ull << lane) - 1ull))] = e;
+        unsigned out = 0;
+        if (lane == 0 && total) out = atomicAdd(live_count, total);
+        out = __builtin_amdgcn_readfirstlane(out);
+        for (int j = 0; j < nu; ++j) {
+            const int base = __shfl(mine.x, j, 64), n = __shfl(mine.y, j, 64);
+            const unsigned long long m = ((unsigned long long)(unsigned)__shfl((int)(my_mask >> 32), j, 64) << 32) |
+                                         (unsigned)__shfl((int)(my_mask & 0xffffffffull), j, 64);
+            if ((m >> lane) & 1ull) live_idx[out + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)(base + lane);
+            else if (lane < n) rec_J[base + lane] = (double)INFINITY;
+            out += (unsigned)__popcll(m);
+        }
     }
 }
 
