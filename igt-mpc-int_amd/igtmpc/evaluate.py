@@ -50,6 +50,16 @@ def initial_states(rng, route_pairs):
     return x, rid
 
 
+def auto_track_env(N, dt):
+    """Scale of the tracking family's acceleration envelope (igt_params.track_env) for a CLOSED loop with horizon N dt.
+    1 is the derived value -- the stationary acceleration of the NLP's own cost -- and the best setting from a 4 s horizon
+    on (mpc.yaml:6 ships N = 40, dt = 0.1); a plan that is optimal over a shorter horizon runs faster into conflicts it
+    cannot see yet, so the scale shrinks with the horizon, not below 0.25.  Measured (tools/envelope_sweep.py, 512 episodes):
+    N = 20: 0.5 -> 10 % infeasible steps / 29 % deadlock flag / 46.8 m against 15.6 % / 41 % / 43.1 m at 1.0;
+    N = 40: 1.0 -> 6.1 % / 4.1 % / 54.3 m.  The library's own default stays 1.0 (one solve knows no closed loop)."""
+    return float(min(1.0, max(0.25, N * dt / 4.0)))
+
+
 def run_closed_loop(sc=1, num_samples=1, N=40, dt=0.1, T_sim=15.0, seed=2026, C=256, n_rk4=4, device=0,
                     dtype='f64', rotation=None, cand_mode='track', refine_iters=0, verbose=False,
                     eval_mode='mpc', value_net=None, device_resident=False, warm_start=True, init=None,
@@ -63,7 +73,8 @@ def run_closed_loop(sc=1, num_samples=1, N=40, dt=0.1, T_sim=15.0, seed=2026, C=
     init = (x[E,M,7], route_pairs[E]) overrides the sampled initial states; terminal_set=False drops the C_inf
     constraint (mpc.py:177-180) -- a test switch.  feas_tol: inequality tolerance of the verdicts (default: the
     library's 1e-6; IPOPT's constr_viol_tol is 1e-3, mpc.py:135); limits: further igt_params fields by name
-    (e.g. dict(track_env=0.0)).  graph=True (with device_resident): the time loop replays one captured step."""
+    (e.g. dict(track_env=0.0); without it the tracking family's envelope scale follows the horizon: auto_track_env).
+    graph=True (with device_resident): the time loop replays one captured step."""
     gt = eval_mode == 'gt_mpc'
     if gt and value_net is None:
         if init is not None:
@@ -81,6 +92,9 @@ def run_closed_loop(sc=1, num_samples=1, N=40, dt=0.1, T_sim=15.0, seed=2026, C=
         pairs = [R.SCENARIO_ROUTES[sc - 1][(e if rotation is None else rotation) % 4] for e in range(E)]
         x, rid = initial_states(rng, pairs)                             # x[E,M,7]
     warm = bool(warm_start) and cand_mode in ('ramp_hold', 'track')
+    limits = dict(limits or {})
+    if cand_mode == 'track' and 'track_env' not in limits:
+        limits['track_env'] = auto_track_env(N, dt)                     # (not applied with the gt_mpc cost: igtmpc.h)
     kp = R.kparams(rid)                                                 # [E,M,3]
     absh = R.TABLES['abs_heading'][rid]
     flags = absh.astype(np.uint32).reshape(-1)
@@ -109,6 +123,7 @@ def run_closed_loop(sc=1, num_samples=1, N=40, dt=0.1, T_sim=15.0, seed=2026, C=
         solver.close()
         stepper.close()
         out['routes'] = pairs
+        out['track_env'] = limits.get('track_env')
         return out
 
     x_data = np.zeros((E, 7 * M, M_sim + 1))
@@ -172,7 +187,7 @@ def run_closed_loop(sc=1, num_samples=1, N=40, dt=0.1, T_sim=15.0, seed=2026, C=
     solver.close()
     stepper.close()
     return dict(x_data=x_data, u_data=u_data, infeasible_ratio=infeasible / M_sim, deadlock=deadlock,
-                routes=pairs, solve_ms=np.array(solve_ms))
+                routes=pairs, solve_ms=np.array(solve_ms), track_env=limits.get('track_env'))
 
 
 def shift_controls(u):

@@ -111,7 +111,7 @@ class MPC_Planner:
     def __init__(self, N=10, dt=0.1, agents=None, goals=None, ca_radius=2.8, ref=None, road_dim=(10, 50),
                  routes=None, ds_right=None, index=None, num_rk4_steps=7, solver='ipopt', ca_type='circle',
                  nn_config_dir=None, use_NN_cost2go=False, weights=(1, 1, 1),
-                 C=256, device=0, dtype='f64', value_net=None, cand_mode='track', refine_iters=0):
+                 C=256, device=0, dtype='f64', value_net=None, cand_mode='track', refine_iters=0, track_env=None):
         assert agents is not None, 'Agents are not defined'           # mpc.py:155
         assert index is not None                                      # mpc.py:80
         if ca_type != 'circle':
@@ -158,12 +158,16 @@ class MPC_Planner:
         self.NN_config = dict(include_route=include_route) if use_NN_cost2go else None
         # planners with the same discretisation, candidate family and value network share one solver handle; the
         # network is keyed by CONTENT (a dict rebuilt with the same weights maps to the same handle)
+        if track_env is None:      # a planner lives in a closed loop: the envelope's scale follows the horizon (evaluate.py)
+            from .evaluate import auto_track_env
+            track_env = auto_track_env(N, dt)
+        self.track_env = float(track_env)
         key = (N, dt, num_rk4_steps, C, self.num_obstacles, device, dtype, cost_mode, self.d_min, cand_mode, refine_iters,
-               _net_digest(value_net))
+               self.track_env, _net_digest(value_net))
         if key not in _SHARED:
             s = BatchSolver(N=N, dt=dt, n_rk4=num_rk4_steps, C=C, n_obs=self.num_obstacles, device=device,
                             dtype=dtype, cost_mode=cost_mode, d_min=self.d_min, cand_mode=cand_mode,
-                            refine_iters=refine_iters)
+                            refine_iters=refine_iters, track_env=self.track_env)
             s.set_cinf(*self.C_inf)
             if use_NN_cost2go:
                 s.set_value_net(**value_net)

@@ -93,9 +93,10 @@ def augment_prev_sol(x_sol_prev, u_sol_prev, kp, P):
 
 
 def run_episode(x_init, routes, P, cinf, M_sim=30, cand_mode='lattice', C=256, refine_iters=0, warm_start=True,
-                u_init=None, eval_mode='mpc', net=None):
+                u_init=None, eval_mode='mpc', net=None, track_env=1.0):
     """x_init[M,7] (planner state order), routes = (route of agent 0, route of agent 1).
     eval_mode 'gt_mpc' needs net = dict(layers, Wn, mu_f, sigma_t, mu_t) (np_oracle.terminal_value).
+    track_env: scale of the tracking family's acceleration envelope (the driver under test picks it from the horizon).
     -> dict(x_data[7M, M_sim+1], u_data[2M, M_sim], infeasible[M], deadlock, events)."""
     M, N, dt = len(routes), P.N, P.dt
     assert M == 2
@@ -142,7 +143,8 @@ def run_episode(x_init, routes, P, cinf, M_sim=30, cand_mode='lattice', C=256, r
                 kw = dict(net=net, tv_sv=np.array([tv], dtype=np.float64),
                           enc=np.array([[code[i], code[j]]], dtype=np.float64))
             if cand_mode in ('ramp_hold', 'track'):
-                r = O.solve_batch_refined(*args, C=C, refine_iters=refine_iters, u_ws=u_ws, cand=cand_mode, **kw)[-1]
+                r = O.solve_batch_refined(*args, C=C, refine_iters=refine_iters, u_ws=u_ws, cand=cand_mode,
+                                          track=dict(env=track_env), **kw)[-1]
             else:
                 r = O.solve_batch(*args, C=C, **kw)
             if r['status'][0] == 0:                                                        # evaluate.py:484-510

@@ -446,7 +446,9 @@ def test_mpc_planner_warm_start_sequence_matches_oracle():
     xd, ud, okd = dflt.solve()
     st0 = agents[i]['state']
     rd = O.solve_batch_refined(np.array([st0.state7()]), np.array([[0.1, 0.0]]), np.array([dflt.K.kparams]), np.array([0], np.uint32),
-                               np.array([[[[p.x for p in preds[1]], [p.y for p in preds[1]]]]]), *dflt.C_inf, P, cand='track')[-1]
+                               np.array([[[[p.x for p in preds[1]], [p.y for p in preds[1]]]]]), *dflt.C_inf, P, cand='track',
+                               track=dict(env=dflt.track_env))[-1]
+    assert dflt.track_env == 0.5          # horizon-aware default (igtmpc.evaluate.auto_track_env): N dt = 2 s of 4
     assert okd == (rd['status'][0] == 0) and (not okd or rel_err(xd, rd['x'][0]).max() < 1e-9)
     pl = igtmpc.MPC_Planner(N=N, dt=0.1, ca_radius=2.8, agents=agents, routes=routes, ref=refs, goals=None,
                             road_dim=(11.4, 50), ds_right=8.6, index=i, num_rk4_steps=4, cand_mode='ramp_hold')
@@ -508,7 +510,8 @@ def test_closed_loop_matches_oracle_loop(cand_mode):
                               terminal_set=terminal)
         cinf = cinf_halfplanes() if terminal else (None, None)
         for q, e in enumerate(sel):
-            ref = CL.run_episode(x[e], pairs[e], P, cinf, M_sim=30, cand_mode=cand_mode)
+            ref = CL.run_episode(x[e], pairs[e], P, cinf, M_sim=30, cand_mode=cand_mode,
+                                 track_env=got['track_env'] if cand_mode == 'track' else 1.0)
             for k in ev:
                 ev[k] += ref['events'][k]
             assert rel_err(got['x_data'][q], ref['x_data']).max() < 1e-9, (e, pairs[e])

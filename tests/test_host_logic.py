@@ -447,3 +447,9 @@ def test_c_abi_argument_validation_without_a_gpu():
     assert lib.igt_comm_init(None, 1, 0, None) != 0
     assert lib.igt_allgather_controls_f64(None, 4, None, None, None) != 0
     assert lib.igt_set_profiling(None, 1) != 0
+
+
+def test_closed_loop_envelope_scale_follows_the_horizon():
+    from igtmpc.evaluate import auto_track_env
+    assert auto_track_env(40, 0.1) == 1.0 and auto_track_env(20, 0.1) == 0.5 and auto_track_env(10, 0.1) == 0.25
+    assert auto_track_env(5, 0.1) == 0.25 and auto_track_env(80, 0.1) == 1.0

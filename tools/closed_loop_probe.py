@@ -12,7 +12,8 @@ dtype = sys.argv[1] if len(sys.argv) > 1 else 'f64'
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 20          # horizon (mpc.yaml:6 ships 40; BASELINE fixes 20)
 cfgs = [('lattice', 0, False, None), ('ramp_hold', 0, False, None), ('ramp_hold', 0, True, None), ('ramp_hold', 1, True, None),
         ('ramp_hold', 0, True, 1e-3), ('track', 0, False, None), ('track', 0, True, None), ('track', 1, True, None),
-        ('track', 0, True, 1e-3), ('track', 0, True, None, {'track_env': 0.0})]
+        ('track', 0, True, 1e-3), ('track', 0, True, None, {'track_env': 0.0}), ('track', 0, True, None, {'track_env': 1.0})]
+# ('track', ..., None) runs with the driver's horizon-aware envelope scale (igtmpc.evaluate.auto_track_env: 0.5 at N = 20, 1 at N = 40)
 if len(sys.argv) > 3:                                       # only the configurations of one family
     cfgs = [c for c in cfgs if c[0] == sys.argv[3]]
 tot = {}
