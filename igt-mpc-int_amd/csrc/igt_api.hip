@@ -680,6 +680,12 @@ int igt_create(const igt_params* p, int device, igt_handle** out) {
     if (!p || !out) return fail(IGT_E_INVALID, "null argument");
     std::string why;
     if (validate(*p, why)) return fail(IGT_E_INVALID, why);
+#if !IGT_DEV_KERNELS
+    if (const char* e = getenv("IGT_DEV_FLAGS"))
+        if (atoi(e) & IGT_DEV_KERNEL_FLAGS)
+            return fail(IGT_E_INVALID, "IGT_DEV_FLAGS selects developer kernels (32 / 1024 / 2048) that this library is built without; "
+                                       "load libigtmpc_dev.so (built with IGT_DEV_KERNELS=1)");
+#endif
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(IGT_E_INVALID, "no such device");

@@ -17,6 +17,15 @@
 
 #include "igt_math64.h"
 
+// Developer kernels (A/B timing and cross-checks, selected at run time through IGT_DEV_FLAGS): the 3-waves-per-SIMD builds
+// of the search kernels (32), the oracle-order float64 kernels (1024) and the literal north_star mapping (2048).  The
+// shipped libigtmpc.so is built without them (IGT_DEV_KERNELS = 0: igt_create refuses those flags); libigtmpc_dev.so, which
+// the tests that compare against them load, is the same source with IGT_DEV_KERNELS = 1.
+#ifndef IGT_DEV_KERNELS
+#define IGT_DEV_KERNELS 0
+#endif
+#define IGT_DEV_KERNEL_FLAGS (32 | 1024 | 2048)
+
 namespace igt {
 
 struct KP {  // kernel parameters (by value -> SGPRs)

@@ -214,10 +214,12 @@ __device__ __forceinline__ void search_waves_f32(IGT_SEARCH_ARGS) {
                                            part_J, part_c, rec_sN, rec_vN, rec_J, rec_viol, rec_count, rec_b);
     });
 }
+#if IGT_DEV_KERNELS
 template <int CAND, bool HI, bool VALUE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void search_fast_kernel_o3(IGT_SEARCH_ARGS) {
     search_waves_f32<CAND, HI, VALUE, false>(IGT_SEARCH_PASS);
 }
+#endif
 template <int CAND, bool HI, bool VALUE>
 __global__ __launch_bounds__(64) void search_fast_kernel_o2(IGT_SEARCH_ARGS) {
     search_waves_f32<CAND, HI, VALUE, false>(IGT_SEARCH_PASS);
@@ -558,7 +560,7 @@ static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>&
     // persistent waves on per-XCD queues, 2 per SIMD.  The 3-per-SIMD build (168 VGPRs, a spill around each unit) was
     // ahead on big batches in round 1; with the sub-step variants unrolled it spills 228 B/lane and is behind at every
     // size but one (B = 32 768: +0.7 %) -- it stays selectable for A/B runs (IGT_DEV_FLAGS = 32)
-    const bool o3 = (P.dev & 32) != 0;
+    const bool o3 = IGT_DEV_KERNELS && (P.dev & 32) != 0;
     const size_t slots = (size_t)A.n_cu * 4 * (o3 ? 3 : 2);
     const size_t grid = total < slots ? total : slots;
     const unsigned* order = nullptr;
@@ -568,11 +570,14 @@ static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>&
                            order_stride, A.work_counter);
         order = A.queue_order;
     }
+#if IGT_DEV_KERNELS
     if (o3)
         hipLaunchKernelGGL((search_fast_kernel_o3<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
                            order, order_stride, A.ckpt, A.ck_parts, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, A.rec_sN,
                            A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
-    else if (A.ckpt && A.ck_parts > 1)
+    else
+#endif
+    if (A.ckpt && A.ck_parts > 1)
         hipLaunchKernelGGL((search_fast_kernel_o2c<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
                            order, order_stride, A.ckpt, A.ck_parts, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf,
                            A.centre(), A.part_J, A.part_c, A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);

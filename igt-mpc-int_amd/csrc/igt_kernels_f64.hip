@@ -12,6 +12,7 @@
 
 namespace igt {
 
+#if IGT_DEV_KERNELS   // the oracle-order kernels (IGT_DEV_FLAGS = 1024)
 template <class Stepper, typename T, int NC, bool SHARED_DF, bool VALUE>
 __global__ __launch_bounds__(256) void search_kernel(KP P, int B, const T* __restrict__ x0,
                                                      const T* __restrict__ u_prev,
@@ -139,6 +140,8 @@ __global__ __launch_bounds__(256) void rollout_all_kernel(KP P, int B, const T* 
 }
 
 
+#endif  // IGT_DEV_KERNELS
+
 // ---------------------------------------------------------------------------------------
 // float64 path (igt_fast64.h): one candidate per lane, W = C/64 units per scenario
 // ---------------------------------------------------------------------------------------
@@ -254,6 +257,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                        rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg);
     });
 }
+#if IGT_DEV_KERNELS
 template <int CAND, bool HI, bool VALUE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void search_f64_kernel_o3(IGT_SEARCH64_ARGS) {
     search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
@@ -261,6 +265,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                                        rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg);
     });
 }
+#endif
 
 // one lane per scenario: final arg-min over the W partials, then the winner re-rolled with the same arithmetic
 // (general sub-step variant: the lanes of the wave belong to different scenarios) -> x*[7,N+1], u*[2,N]
@@ -336,6 +341,7 @@ __global__ __launch_bounds__(256) void rollout_all_f64_kernel(KP P, int B, const
     }
 }
 
+#if IGT_DEV_KERNELS
 // ---------------------------------------------------------------------------------------
 // The LITERAL mapping of BASELINE.json's north_star, kept as a measurement variant (IGT_DEV_FLAGS = 2048):
 // one wavefront per (scenario, candidate) trajectory -- lane 0 rolls the horizon (the recurrence is sequential) and
@@ -423,9 +429,12 @@ __global__ __launch_bounds__(64 * LIT_WAVES) void search_literal_f64_kernel(
     }
 }
 
+#endif  // IGT_DEV_KERNELS
+
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
+#if IGT_DEV_KERNELS
 template <bool VALUE>
 static hipError_t launch_search_exact(const KP& P, int B, const SolveArgs<double>& A, hipStream_t st) {
     typedef ExactStepper<double> St;
@@ -441,6 +450,7 @@ static hipError_t launch_search_exact(const KP& P, int B, const SolveArgs<double
     return hipGetLastError();
 }
 
+#endif
 bool search_builds_queues(const KP& P, int B, const SolveArgs<double>& A) {
     const int W = P.C / 64;
     return A.queue_order && W <= 256 && ((B + 7) / 8) * W <= QB_THREADS * QB_TRIPS && !(P.dev & 16) && !(P.dev & (1024 | 2048));
@@ -450,15 +460,17 @@ bool search_builds_queues(const KP& P, int B, const SolveArgs<double>& A) {
 template <int CAND, bool HI, bool VALUE>
 static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A, hipStream_t st) {
     const int W = P.C / 64;
+#if IGT_DEV_KERNELS
     if ((P.dev & 2048) && !VALUE && P.N <= LIT_MAX_N) {       // measurement variant: the literal wave-per-trajectory mapping
         hipLaunchKernelGGL((search_literal_f64_kernel<CAND, HI>), dim3(B), dim3(64 * LIT_WAVES), 0, st, P, B, W, A.x0, A.u_prev,
                            A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c);
         return hipGetLastError();
     }
+#endif
     const size_t total = (size_t)B * W;
     // 2 waves per SIMD (232 VGPRs, no spill); the 3-per-SIMD build spills 244 B/lane and is 3-8 % behind at every batch
     // size (IGT_DEV_FLAGS = 32 selects it for A/B runs)
-    const bool o3 = (P.dev & 32) != 0;
+    const bool o3 = IGT_DEV_KERNELS && (P.dev & 32) != 0;
     const size_t slots = (size_t)A.n_cu * 4 * (o3 ? 3 : 2);
     const size_t grid = total < slots ? total : slots;
     const unsigned* order = nullptr;
@@ -468,11 +480,14 @@ static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A
                            A.queue_order, order_stride, A.work_counter);
         order = A.queue_order;
     }
+#if IGT_DEV_KERNELS
     if (o3)
         hipLaunchKernelGGL((search_f64_kernel_o3<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter, order,
                            order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c,
                            A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b, A.unit_seg);
-    else {
+    else
+#endif
+    {
         // the reference's discretisation (4 sub-steps, short polynomials) has its own build of the kernel
         constexpr int NRK4 = HI ? 0 : 4;
         const bool rk4 = NRK4 == 4 && P.n_rk4 == 4;
@@ -491,7 +506,9 @@ static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A
 }
 template <bool VALUE>
 static hipError_t dispatch_search64(const KP& P, int B, const SolveArgs<double>& A, hipStream_t st) {
+#if IGT_DEV_KERNELS
     if (P.dev & 1024) return launch_search_exact<VALUE>(P, B, A, st);     // developer switch: oracle-order kernels
+#endif
     if (P.hi_order) {
         if (P.cand_mode == CAND_LATTICE) return launch_search64<CAND_LATTICE, true, VALUE>(P, B, A, st);
         if (P.cand_mode == CAND_RAMP_HOLD) return launch_search64<CAND_RAMP_HOLD, true, VALUE>(P, B, A, st);
@@ -527,11 +544,13 @@ static hipError_t launch_emit64(const KP& P, int B, int W, const SolveArgs<doubl
 }
 template <>
 hipError_t launch_emit<double>(const KP& P, int B, int W, const SolveArgs<double>& A, hipStream_t st) {
+#if IGT_DEV_KERNELS
     if (P.dev & 1024) {     // developer switch: oracle-order kernels (argmin_out is already final there)
         hipLaunchKernelGGL((emit_kernel<ExactStepper<double>, double>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, A.x0,
                            A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.argmin_out, A.x_out, A.u_out);
         return hipGetLastError();
     }
+#endif
     if (P.hi_order) {
         if (P.cand_mode == CAND_LATTICE) return launch_emit64<CAND_LATTICE, true>(P, B, W, A, st);
         if (P.cand_mode == CAND_RAMP_HOLD) return launch_emit64<CAND_RAMP_HOLD, true>(P, B, W, A, st);
@@ -555,12 +574,14 @@ static hipError_t launch_rollout_all64(const KP& P, int B, const SolveArgs<doubl
 template <>
 hipError_t launch_rollout_all<double>(const KP& P, int B, const SolveArgs<double>& A, double* X_all, double* U_all,
                                       double* cost_all, uint32_t* viol_all, hipStream_t st) {
+#if IGT_DEV_KERNELS
     if (P.dev & 1024) {     // developer switch: oracle-order kernels
         hipLaunchKernelGGL((rollout_all_kernel<ExactStepper<double>, double>), dim3((B + 3) / 4), dim3(256), 0, st, P, B,
                            A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), X_all, U_all, cost_all, viol_all,
                            A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol);
         return hipGetLastError();
     }
+#endif
     if (P.hi_order) {
         if (P.cand_mode == CAND_LATTICE) return launch_rollout_all64<CAND_LATTICE, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);
         if (P.cand_mode == CAND_RAMP_HOLD) return launch_rollout_all64<CAND_RAMP_HOLD, true>(P, B, A, X_all, U_all, cost_all, viol_all, st);

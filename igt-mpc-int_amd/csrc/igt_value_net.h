@@ -680,7 +680,6 @@ __global__ __launch_bounds__(256) void value_select_kernel(int n_units, int W, c
         const double my_thr = lane < nu ? thr[(t0 + lane) / W] : 0.0;
         unsigned long long my_mask = 0ull;
         unsigned total = 0;
-#pragma unroll 4
         for (int j = 0; j < nu; ++j) {
             const int base = __shfl(mine.x, j, 64), n = __shfl(mine.y, j, 64);
             const double tj = __shfl(my_thr, j, 64);

@@ -72,17 +72,31 @@ SYMBOLS = {
     'igt_algorithmic_bytes_per_solve': (_i, [_vp, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }
 
-_lib = None
+_libs = {}
+DEV_KERNEL_FLAGS = 32 | 1024 | 2048      # csrc/igt_device.h IGT_DEV_KERNEL_FLAGS
+LIB_PATH_DEV = os.path.join(os.path.dirname(LIB_PATH), 'libigtmpc_dev.so')
 
 
-def load():
-    """Loads libigtmpc.so once and sets every prototype.  Raises ImportError when the
-    library is absent -- there is deliberately no fallback path."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+def wants_dev_kernels():
+    """True when IGT_DEV_FLAGS (read by the library at igt_create) selects kernels only libigtmpc_dev.so carries."""
+    try:
+        return bool(int(os.environ.get('IGT_DEV_FLAGS', '0') or 0) & DEV_KERNEL_FLAGS)
+    except ValueError:
+        return False
+
+
+def load(dev=None):
+    """Loads libigtmpc.so (the shipped library) once and sets every prototype.  Raises ImportError when the library is
+    absent -- there is deliberately no fallback path.  dev=True, or dev=None with IGT_DEV_FLAGS asking for developer
+    kernels: libigtmpc_dev.so, the same sources built with IGT_DEV_KERNELS=1 (tests and A/B tools only)."""
+    if dev is None:
+        dev = wants_dev_kernels()
+    dev = bool(dev)
+    if dev in _libs:
+        return _libs[dev]
+    path = LIB_PATH_DEV if dev else LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError(f'{path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                           f'or `make -C igt-mpc-int_amd/csrc`')
     try:
         # torch ships its own libamdhip64; it must be the first HIP runtime the process
@@ -91,14 +105,14 @@ def load():
     except ImportError:
         pass
     try:
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
     except OSError as e:
-        raise ImportError(f'cannot load {LIB_PATH}: {e}') from e
+        raise ImportError(f'cannot load {path}: {e}') from e
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)     # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[dev] = lib
     return lib
 
 
@@ -106,7 +120,7 @@ class IgtError(RuntimeError):
     pass
 
 
-def check(rc):
+def check(rc, lib=None):
     if rc != 0:
-        msg = load().igt_last_error()
+        msg = (lib or load(False)).igt_last_error()
         raise IgtError(f'igtmpc error {rc}: {msg.decode() if msg else "?"}')

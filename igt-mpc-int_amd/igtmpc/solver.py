@@ -24,13 +24,13 @@ class BatchSolver:
     def __init__(self, N=20, dt=0.1, n_rk4=4, C=256, n_obs=1, device=0, dtype='f32',
                  cand_mode='lattice', cost_mode='progress', **limits):
         self._h = None
-        self.lib = L.load()
+        self.lib = L.load()          # the shipped library -- or libigtmpc_dev.so when IGT_DEV_FLAGS asks for developer kernels
         if dtype not in _DT:
             raise ValueError("dtype must be 'f32' or 'f64'")
         self.dtype = dtype
         self.np_dtype = _DT[dtype]
         p = L.igt_params()
-        L.check(self.lib.igt_params_default(ct.byref(p)))
+        self._check(self.lib.igt_params_default(ct.byref(p)))
         p.N, p.dt, p.n_rk4, p.C, p.n_obs = N, dt, n_rk4, C, n_obs
         p.cand_mode = {'lattice': L.IGT_CAND_LATTICE, 'table': L.IGT_CAND_TABLE,
                        'ramp_hold': L.IGT_CAND_RAMP_HOLD, 'track': L.IGT_CAND_TRACK}[cand_mode]
@@ -42,7 +42,7 @@ class BatchSolver:
         self.params = p
         self.device = device
         h = ct.c_void_p()
-        L.check(self.lib.igt_create(ct.byref(p), device, ct.byref(h)))
+        self._check(self.lib.igt_create(ct.byref(p), device, ct.byref(h)))
         self._h = h
         self.N, self.C, self.n_obs = N, C, n_obs
         self._solve = getattr(self.lib, f'igt_solve_batch_ws_{dtype}')
@@ -51,6 +51,9 @@ class BatchSolver:
         self._fstep = getattr(self.lib, f'igt_frenet_step_{dtype}')
         self._fcast = getattr(self.lib, f'igt_forecast_batch_{dtype}')
         self._routes_set = False
+
+    def _check(self, rc):
+        L.check(rc, self.lib)
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -77,13 +80,13 @@ class BatchSolver:
         b = np.ascontiguousarray(b, dtype=np.float64).reshape(-1)
         if len(A) != len(b):
             raise ValueError('A and b disagree')
-        L.check(self.lib.igt_set_cinf(self._h, A.ctypes.data, b.ctypes.data, len(b)))
+        self._check(self.lib.igt_set_cinf(self._h, A.ctypes.data, b.ctypes.data, len(b)))
 
     def set_candidate_table(self, U):
         U = np.ascontiguousarray(U, dtype=np.float64)
         if U.shape != (self.C, 2, self.N):
             raise ValueError(f'candidate table must be [{self.C},2,{self.N}]')
-        L.check(self.lib.igt_set_candidate_table(self._h, U.ctypes.data))
+        self._check(self.lib.igt_set_candidate_table(self._h, U.ctypes.data))
 
     def set_value_net(self, layers, Wn=None, mu_f=None, sigma_t=1.0, mu_t=0.0):
         """Terminal value network of the gt_mpc cost (mpc.py:108-127, 367-369; model.py:14-51).
@@ -97,21 +100,21 @@ class BatchSolver:
                                for W, b in layers])
         dims_a = np.asarray(dims, dtype=np.int32)
         Wn_c, mu_c = np.ascontiguousarray(Wn), np.ascontiguousarray(mu_f)
-        L.check(self.lib.igt_set_value_net(self._h, len(layers), dims_a.ctypes.data, flat.ctypes.data,
+        self._check(self.lib.igt_set_value_net(self._h, len(layers), dims_a.ctypes.data, flat.ctypes.data,
                                            Wn_c.ctypes.data, mu_c.ctypes.data, float(sigma_t), float(mu_t)))
 
     def set_profiling(self, on=True):
-        L.check(self.lib.igt_set_profiling(self._h, int(on)))
+        self._check(self.lib.igt_set_profiling(self._h, int(on)))
 
     def kernel_ms(self):
         a, b = ct.c_float(), ct.c_float()
-        L.check(self.lib.igt_get_kernel_ms(self._h, ct.byref(a), ct.byref(b)))
+        self._check(self.lib.igt_get_kernel_ms(self._h, ct.byref(a), ct.byref(b)))
         return a.value, b.value
 
     def algorithmic_bytes_per_solve(self):
         r, w = ct.c_int64(), ct.c_int64()
         es = 4 if self.dtype == 'f32' else 8
-        L.check(self.lib.igt_algorithmic_bytes_per_solve(self._h, es, ct.byref(r), ct.byref(w)))
+        self._check(self.lib.igt_algorithmic_bytes_per_solve(self._h, es, ct.byref(r), ct.byref(w)))
         return r.value, w.value
 
     # ------------------------------------------------------------------ marshalling
@@ -197,7 +200,7 @@ class BatchSolver:
             for k, i in (('x', 8), ('u', 9), ('cost', 10), ('argmin', 11), ('status', 12)):
                 if keep_is_copy(out[k], ptrs[i]):
                     raise ValueError(f'out[{k!r}] must be a contiguous array of the solver dtype')
-        L.check(self._solve(self._h, B, *ptrs, mode, self._stream_ptr(stream, mode == L.IGT_MEM_DEVICE)))
+        self._check(self._solve(self._h, B, *ptrs, mode, self._stream_ptr(stream, mode == L.IGT_MEM_DEVICE)))
         return out
 
     def rollout_all(self, x0, u_prev, kparams, flags, obs_xy=None, tv_sv=None, enc=None, want_X=True, want_U=True,
@@ -217,7 +220,7 @@ class BatchSolver:
                   (B, Cn, 7, N + 1), (B, Cn, 2, N), (B, Cn), (B, Cn)]
         dts = [dt, dt, dt, np.uint32, dt, dt, dt, dt, dt, dt, dt, np.uint32]
         mode, ptrs, keep = self._prep(arrs, shapes, dts)
-        L.check(self._rollout(self._h, B, *ptrs, mode, self._stream_ptr(stream, False)))
+        self._check(self._rollout(self._h, B, *ptrs, mode, self._stream_ptr(stream, False)))
         return dict(X=X, U=U, cost=cost, viol=viol)
 
     def set_routes(self, table=None):
@@ -230,7 +233,7 @@ class BatchSolver:
         table = np.ascontiguousarray(table, dtype=np.float64)
         if table.ndim != 2 or table.shape[1] != 12:
             raise ValueError('route table must be [n_routes, 12]')
-        L.check(self.lib.igt_set_routes(self._h, len(table), table.ctypes.data))
+        self._check(self.lib.igt_set_routes(self._h, len(table), table.ctypes.data))
         self._routes_set = True
 
     def forecast(self, ego_xyh, opp, opp_a, opp_route, plan_x=None, plan_u=None, has_plan=None, stream=None):
@@ -250,7 +253,7 @@ class BatchSolver:
         shapes = [(B, 3), (B, 4), (B,), (B,), (B, 7, N + 1), (B, 2, N), (B,), (B, 1, 2, N + 1), (B, 2)]
         dts = [dt, dt, dt, np.int32, dt, dt, np.int32, dt, dt]
         mode, ptrs, keep = self._prep(arrs, shapes, dts)
-        L.check(self._fcast(self._h, B, *ptrs, mode, self._stream_ptr(stream, mode == L.IGT_MEM_DEVICE)))
+        self._check(self._fcast(self._h, B, *ptrs, mode, self._stream_ptr(stream, mode == L.IGT_MEM_DEVICE)))
         return obs, tv
 
     def frenet_step(self, x, u, kparams, stream=None):
@@ -264,7 +267,7 @@ class BatchSolver:
         else:
             out = np.empty((n, 7), dt)
         mode, ptrs, keep = self._prep([x, u, kparams, out], [(n, 7), (n, 2), (n, 3), (n, 7)], [dt] * 4)
-        L.check(self._fstep(self._h, n, *ptrs, mode, self._stream_ptr(stream, mode == L.IGT_MEM_DEVICE)))
+        self._check(self._fstep(self._h, n, *ptrs, mode, self._stream_ptr(stream, mode == L.IGT_MEM_DEVICE)))
         return out
 
     def cartesian_euler(self, z0, u, stream=None):
@@ -277,7 +280,7 @@ class BatchSolver:
         else:
             out = np.empty((n, 4, T + 1), dt)
         mode, ptrs, keep = self._prep([z0, u, out], [(n, 4), (n, 2, T), (n, 4, T + 1)], [dt, dt, dt])
-        L.check(self._cart(self._h, n, T, *ptrs, mode, self._stream_ptr(stream, mode == L.IGT_MEM_DEVICE)))
+        self._check(self._cart(self._h, n, T, *ptrs, mode, self._stream_ptr(stream, mode == L.IGT_MEM_DEVICE)))
         return out
 
 

@@ -141,6 +141,8 @@ def test_c_abi_exports_every_declared_symbol():
     lib = L.load()
     for name in declared:
         assert hasattr(lib, name)
+    dev = L.load(dev=True)                                        # the developer build exports the same ABI
+    assert dev is not lib and all(hasattr(dev, name) for name in declared)
     assert lib.igt_version() == 201 == int(re.search(r"#define IGT_VERSION (\d+)", hdr).group(1))
     p = L.igt_params()
     assert lib.igt_params_default(ct.byref(p)) == 0
@@ -160,7 +162,7 @@ def test_c_abi_exports_every_declared_symbol():
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     """No CPU fallback: without libigtmpc.so the product raises ImportError naming the build command."""
     from igtmpc import _lib as L
-    monkeypatch.setattr(L, '_lib', None)
+    monkeypatch.setattr(L, '_libs', {})
     monkeypatch.setattr(L, 'LIB_PATH', str(tmp_path / 'libigtmpc.so'))
     with pytest.raises(ImportError, match='build'):
         L.load()
@@ -453,3 +455,25 @@ def test_closed_loop_envelope_scale_follows_the_horizon():
     from igtmpc.evaluate import auto_track_env
     assert auto_track_env(40, 0.1) == 1.0 and auto_track_env(20, 0.1) == 0.5 and auto_track_env(10, 0.1) == 0.25
     assert auto_track_env(5, 0.1) == 0.25 and auto_track_env(80, 0.1) == 1.0
+
+
+def test_shipped_library_is_built_without_the_developer_kernels(monkeypatch):
+    """the 3-waves-per-SIMD builds, the oracle-order float64 kernels and the literal north_star mapping
+    are compiled into libigtmpc_dev.so only; the shipped library refuses the IGT_DEV_FLAGS that select them (checked
+    before any device call), and the Python face picks the developer library when such a flag is set."""
+    from igtmpc import _lib as L
+    shipped, dev = L.load(False), L.load(True)
+    find = lambda path, needle: needle in open(path, 'rb').read()
+    for sym in (b'search_f64_kernel_o3', b'search_fast_kernel_o3', b'search_literal_f64_kernel'):
+        assert find(L.LIB_PATH_DEV, sym) and not find(L.LIB_PATH, sym), sym
+    assert os.path.getsize(L.LIB_PATH) < os.path.getsize(L.LIB_PATH_DEV)
+    p = L.igt_params()
+    shipped.igt_params_default(ct.byref(p))
+    h = ct.c_void_p()
+    for flag in ('32', '1024', '2048', str(1024 | 4)):
+        monkeypatch.setenv('IGT_DEV_FLAGS', flag)
+        assert shipped.igt_create(ct.byref(p), 0, ct.byref(h)) == -1      # IGT_E_INVALID
+        assert b'libigtmpc_dev.so' in shipped.igt_last_error()
+        assert L.wants_dev_kernels() and L.load() is dev
+    monkeypatch.setenv('IGT_DEV_FLAGS', '4')                       # switches of the production kernels stay available
+    assert not L.wants_dev_kernels() and L.load() is shipped
