@@ -319,6 +319,26 @@ struct Scenario {           // wave-uniform inputs of one scenario
     const T* ws;            // [2, N] warm start of this scenario (base sequence of the ramp-hold targets), or null
 };
 
+// Whether no candidate of the scenario that holds the speed box can come within d_min of any forecast position (wave-uniform;
+// the lanes share the horizon).  A control step moves the vehicle by at most dt max(|v_k|, |v_k+1|) (the RK4 stage speeds lie
+// between the two), speed-feasible candidates have |v_k| <= max(|v_min|, |v_max|) + tol for k < N, and |v_N| exceeds that by at
+// most max|a| dt: the reach over the horizon is N dt (v_abs + a_abs dt), taken with a metre to spare.  A candidate outside
+// the speed box is infeasible whatever its distance to the obstacle, so the search's answer is the same either way.
+template <typename T>
+__device__ __forceinline__ bool obstacles_out_of_reach(const KP& P, const Scenario<T>& S, int lane) {
+    const double reach = (fmax(fabs(P.v_min), fabs(P.v_max)) + fmax(fabs(P.a_min), fabs(P.a_max)) * P.dt) * (P.N * P.dt) + 1.0;
+    const double lim = sqrt(P.dmin2) + reach, lim2 = lim * lim;
+    bool near = false;
+    for (int e = lane; e < P.n_obs * P.N; e += 64) {
+        const int o = e / P.N, k = e - o * P.N + 1;
+        const double dx = S.x0[0] - (double)S.obs[(o * 2 + 0) * (P.N + 1) + k], dy = S.x0[1] - (double)S.obs[(o * 2 + 1) * (P.N + 1) + k];
+        near |= !(dx * dx + dy * dy > lim2);                      // NaN counts as near
+    }
+    return !__any(near);
+}
+
+
+
 // what the candidate generators are centred on: refinement parameters [B,4] (null: first pass) and the batch's warm
 // starts [B,2,N] (null: none)
 template <typename T>

@@ -155,7 +155,12 @@ __device__ __forceinline__ void search_unit(const KP& P, int W, int b, int p, do
     double J[2], sN[2], vN[2];
     unsigned viol[2];
     const Ckpt ck{CKPT && ck_parts > 1 ? ckpt : nullptr, (size_t)n_units, gw, lane, ck_parts > 1 ? P.N / ck_parts : 0};
-    rollout_pair<CAND, HI, true, true, float, NullSink, true, CKPT>(P, S, cidx, table, cinf, sink, J, viol, sN, vN, ck);
+    // units whose obstacles are out of every speed-feasible candidate's reach roll without the Cartesian rows (igt_device.h
+    // obstacles_out_of_reach); the builds that leave checkpoints for emit need x, y
+    if (!CKPT && !(P.dev & 65536) && obstacles_out_of_reach<float>(P, S, lane))
+        rollout_pair<CAND, HI, true, true, float, NullSink, true, false, false, false>(P, S, cidx, table, cinf, sink, J, viol, sN, vN, ck);
+    else
+        rollout_pair<CAND, HI, true, true, float, NullSink, true, CKPT>(P, S, cidx, table, cinf, sink, J, viol, sN, vN, ck);
     if (VALUE) {   // terminal value network (mpc.py:369): append the feasible candidates for the value kernels
         const bool dup = cidx[1] == cidx[0];                       // odd chunk count: second half is a duplicate
         const bool ok0 = viol[0] == 0 && finite_d(J[0]), ok1 = viol[1] == 0 && finite_d(J[1]) && !dup;

@@ -196,7 +196,7 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
     const int nj = P.G / W;
     // 70 % of the benchmark's scenarios: the other vehicle is out of reach over the whole horizon (or filter_preds moved it
     // away), so the unit rolls without the Cartesian rows -- a sixth of the control step's instructions
-    const bool far = !(P.dev & 65536) && f64::obstacles_out_of_reach(P, S, lane);
+    const bool far = !(P.dev & 65536) && obstacles_out_of_reach<double>(P, S, lane);
     if (TABULATED && steering_slices64<CAND>(P, W) && nj * P.N <= f64::STAB_MAX_ENTRIES && !(P.dev & 4)) {
         __shared__ double stab[f64::STAB_MAX_ENTRIES * 3];
         f64::fill_steer_table<CAND>(P, S, nj, p, lane, P.lr_ratio, stab);

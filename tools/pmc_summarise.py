@@ -5,7 +5,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 def family(name):
-    for key in ('search_f64', 'emit_f64', 'search_fast', 'emit_fast', 'emit_seg', 'build_queues', 'value_mfma', 'value_compact', 'value_kernel',
+    for key in ('search_f64', 'emit_f64', 'search_fast', 'emit_fast', 'emit_seg', 'build_queues', 'value_mfma', 'value_bound', 'value_select', 'value_compact', 'value_kernel',
                 'keys_to_partials', 'refine_targets', 'rollout_all', 'forecast', 'search_kernel', 'emit_kernel'):
         if key in name:
             return key
