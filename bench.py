@@ -572,12 +572,12 @@ def main():
     # configs[2] = 65 536 scenarios; configs[4] = gt_mpc at 65 536 (V_GT_sc1; lattice and tracking candidates)
     configs = []
     if n_gpus == 1 and not args.no_configs and not args.batch and not args.gt and args.cand == 'lattice':
-        ks, kw = max(4, min(args.steps, 12)), max(2, min(args.warmup, 3))
+        ks, kw = max(8, min(args.steps, 16)), 3
         for name, kwm in (('configs[2]', dict(Bm=65536, cand_mode='lattice', gt=0)),
                           ('configs[4]', dict(Bm=65536, cand_mode='lattice', gt=1)),
                           ('configs[4] through the tracking family', dict(Bm=65536, cand_mode='track', gt=1)),
                           ('configs[4] with V_GT_sc3 (3 hidden layers)', dict(Bm=65536, cand_mode='lattice', gt=3))):
-            m = measure(args.dtype, kwm['Bm'], ks, kw, in_flight=1, cand_mode=kwm['cand_mode'], gt=kwm['gt'], settle_ms=60.0)
+            m = measure(args.dtype, kwm['Bm'], ks, kw, in_flight=1, cand_mode=kwm['cand_mode'], gt=kwm['gt'], settle_ms=100.0)
             configs.append({'config': name, 'workload': workload_name(kwm['Bm'], 1, kwm['gt'], kwm['cand_mode']),
                             'value': m['value'], 'unit': 'solves/s', 'ms_per_step': m['ms_per_step'], 'dtype': args.dtype,
                             'steps': ks, 'warmup': kw, 'solves_in_flight': 1,

@@ -44,6 +44,7 @@ if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
   echo "[collect] in-flight sweep done"
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = probes ]; then
+  hipcc --offload-arch=gfx950 -O3 tools/mfma64_microbench.hip -o /tmp/mfma64_mb > $O/${TAG}_mfma64_build.log 2>&1 && /tmp/mfma64_mb > $O/${TAG}_mfma64_microbench.txt 2>&1
   python3 tools/f64_probe.py 4096 32768 2>&1 | grep -v amdgpu.ids > $O/${TAG}_f64_probe.txt
   python3 tools/f64_probe.py --flags=0,8 65536 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_f64_probe.txt
   python3 tools/family_probe.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_family_probe.txt

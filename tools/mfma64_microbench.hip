@@ -1,11 +1,13 @@
 // Developer probe: issue cost of v_mfma_f64_16x16x4_f64 on gfx950 -- one dependent accumulator chain per wave vs
-// 2 / 4 independent chains, at 1, 2 and 4 waves per SIMD.   hipcc --offload-arch=gfx950 -O3 tools/mfma64_microbench.hip -o /tmp/mb && /tmp/mb
+// 2 / 4 / 8 independent chains, at 1, 2, 4 and 8 waves per SIMD, with the shader clock the kernel actually ran at
+// (s_memtime ticks of wave 0 against the constant 100 MHz s_memrealtime).   hipcc --offload-arch=gfx950 -O3 tools/mfma64_microbench.hip -o /tmp/mb && /tmp/mb
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 template <int CHAINS>
 __global__ __launch_bounds__(256) void k(double* out, long long* cyc, int iters) {
+    const long long w0 = wall_clock64();
     f64x4 acc[CHAINS];
     for (int c = 0; c < CHAINS; ++c) acc[c] = {0.0, 0.0, 0.0, 0.0};
     double a = 1.0 + threadIdx.x * 1e-3, b = 0.5;
@@ -19,13 +21,13 @@ __global__ __launch_bounds__(256) void k(double* out, long long* cyc, int iters)
     double s = 0;
     for (int c = 0; c < CHAINS; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = wall_clock64() - w0; }
 }
 
 template <int CHAINS>
 void run(int waves_per_simd) {
     double* out; long long* cyc;
-    hipMalloc(&out, 1 << 22); hipMalloc(&cyc, 8);
+    hipMalloc(&out, 1 << 23); hipMalloc(&cyc, 16);
     const int iters = 4096;
     // one workgroup of 256 threads = 4 waves = one per SIMD of a CU; waves_per_simd workgroups per CU
     const int blocks = 256 * waves_per_simd;
@@ -37,13 +39,17 @@ void run(int waves_per_simd) {
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+    long long cc[2]; hipMemcpy(cc, cyc, 16, hipMemcpyDeviceToHost);
+    const long long c = cc[0];
+    const double ghz = (double)cc[0] / (double)cc[1] * 0.1;          // shader ticks per 100 MHz tick
     const double mfmas_per_simd = (double)iters * CHAINS * waves_per_simd;
     const double flop = (double)blocks * 4 * iters * CHAINS * 2048.0;
-    printf("chains %d, waves/SIMD %d: %.3f ms, %.1f TFLOP/s, wall cycles per MFMA per SIMD (at 2.4 GHz) %.1f, clock64 ticks per MFMA in wave 0: %.1f\n",
-           CHAINS, waves_per_simd, ms, flop / ms / 1e9, ms * 1e-3 * 2.4e9 / mfmas_per_simd, (double)c / (iters * CHAINS));
+    printf("chains %d, waves/SIMD %d: %.3f ms, %.1f TFLOP/s, shader clock %.2f GHz (data-sheet rate at that clock: %.1f TFLOP/s), "
+           "shader cycles per MFMA per SIMD %.1f, clock64 ticks per MFMA in wave 0: %.1f\n",
+           CHAINS, waves_per_simd, ms, flop / ms / 1e9, ghz, 78.6 * ghz / 2.4, ms * 1e-3 * ghz * 1e9 / mfmas_per_simd,
+           (double)c / (iters * CHAINS));
 }
 int main() {
-    for (int w : {1, 2, 4}) { run<1>(w); run<2>(w); run<4>(w); }
+    for (int w : {1, 2, 4, 8}) { run<1>(w); run<2>(w); run<4>(w); run<8>(w); }
     return 0;
 }

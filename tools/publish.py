@@ -15,7 +15,7 @@ def cp(src, dst):
 for k in ('bench_b4096', 'bench_b4096_driver_args', 'bench_b65536', 'bench_gt_sc1_b65536', 'bench_gt_sc3_b65536'):
     cp(f'{tag}_{k}.json', f'{rnd}_{k}.json')
 for k in ('inflight_sweep', 'f64_probe', 'family_probe', 'latency', 'f32_margin', 'closed_loop', 'closed_loop_n40', 'closed_loop_breakdown',
-          'closed_loop_scale', 'envelope_sweep', 'valu_microbench'):
+          'closed_loop_scale', 'envelope_sweep', 'valu_microbench', 'mfma64_microbench'):
     cp(f'{tag}_{k}.txt', f'{rnd}_{k}.txt')
 for k in ('f64_b4096', 'f64_track_b4096', 'f64_b65536', 'f32_b4096', 'f32_gt1_b65536', 'f64_gt1_b65536'):
     cp(f'{tag}_{k}/summary.json', f'{rnd}_pmc_{k}.json')
