@@ -65,14 +65,21 @@ struct Ctl {
 //     df_cmd = atan(tan(beta_cmd) / r),   df_k = df_{k-1} + clamp(df_cmd - df_{k-1}, +-rate)   (mpc.py:301-312)
 // off_j = c_b + m(u_j) span_b are the G offsets (dense around 0; re-centred by refinement passes like the ramp-hold
 // ones).  The realised (a_k, df_k) are an ordinary control sequence: u_out, cost and verdicts are those of the roll-out.
-__device__ __forceinline__ double track_steer(const KP& P, double df_prev, double ey, double ep, double off) {
+// sbt, cbt (optional outputs): (sin, cos) of the commanded slip angle.  When the step is limited neither by the steering rate
+// nor by the box -- *followed = true -- the steering angle IS the command and the slip angle it produces, atan(r tan df),
+// IS beta_cmd: the roll-out takes (sbt, cbt) as its (sin, cos)(beta) and skips sincos(df) and the normalisation
+// (igt_fast64.h; a wave whose lanes all follow skips them altogether).
+__device__ __forceinline__ double track_steer(const KP& P, double df_prev, double ey, double ep, double off,
+                                              double* sbt_out = nullptr, double* cbt_out = nullptr, bool* followed = nullptr) {
     const double beta = clampd(-ep - P.trk_ke * ey + off, -P.trk_blim, P.trk_blim);
     // cmd = atan(tan(beta) / r) = atan2(sin beta, r cos beta); cos beta > 0 (beta_lim < pi/2, igt_api.hip)
     double sbt, cbt;
     if (P.trk_blim < m64::QUADRANT0) m64::sincos_kernel(beta, sbt, cbt);
     else m64::sincos_reduced(beta, sbt, cbt);
     const double cmd = m64::atan2_xpos(sbt, P.lr_ratio * cbt);
-    return clampd(df_prev + clampd(cmd - df_prev, -P.rate_df, P.rate_df), -P.df_max, P.df_max);
+    const double df = clampd(df_prev + clampd(cmd - df_prev, -P.rate_df, P.rate_df), -P.df_max, P.df_max);
+    if (sbt_out) { *sbt_out = sbt; *cbt_out = cbt; *followed = df == cmd; }
+    return df;
 }
 
 // Acceleration target of the tracking family at step k.  One more unit of a_k buys dt (T - t_k - dt/2) of progress

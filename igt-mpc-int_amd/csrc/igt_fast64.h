@@ -376,6 +376,8 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
     // turns it by beta_k - beta_{k-1} -- no sincos(epsi) per control step (39 of ~460 instructions on a straight route)
     sincos_reduced(S.x0[4], w.s1, w.c1);
     double cb_prev = 1.0, sb_prev = 0.0;
+    double trk_sb = 0.0, trk_cb = 1.0;
+    bool trk_followed = false;
 
     for (int k = 0; k < P.N; ++k) {
         // ---- controls of step k
@@ -393,7 +395,7 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
             ramp_base<double>(S.ws, P.N, k, S.a_prev, S.df_prev, ba, bdf);
             const double ta = track_accel_target(P, k, ba, da);
             a = clampd(a + clampd(ta - a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
-            df = track_steer(P, df, ey, ep, ddf);
+            df = track_steer(P, df, ey, ep, ddf, &trk_sb, &trk_cb, &trk_followed);
         } else {
             const double an = table[((size_t)cidx * 2 + 0) * P.N + k];
             const double dn = table[((size_t)cidx * 2 + 1) * P.N + k];
@@ -408,6 +410,17 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
         if (STAB && (CAND == CAND_LATTICE || CAND == CAND_RAMP_HOLD)) {
             sb = stab[k * stab_stride + 1];
             cb = stab[k * stab_stride + 2];
+        } else if (CAND == CAND_TRACK) {
+            // a lane whose steering followed the command has beta = beta_cmd: its (sin, cos) are known already.  The other
+            // lanes (rate- or box-limited) go through sincos(df); the wave skips that when no lane needs it -- which lane
+            // takes which value does not depend on the vote, so search, emit and rollout-all agree bit for bit
+            sb = trk_sb; cb = trk_cb;
+            if (!__all(trk_followed)) {
+                double sb2, cb2;
+                slip_trig<CAND>(P, fp.lr_ratio, df, sb2, cb2);
+                sb = trk_followed ? sb : sb2;
+                cb = trk_followed ? cb : cb2;
+            }
         } else {
             slip_trig<CAND>(P, fp.lr_ratio, df, sb, cb);
         }

@@ -1,12 +1,12 @@
-// igt_kernels.hip -- gfx950 kernels of the batched shooting solver and their launchers.
+// igt_kernels.hip -- gfx950 kernels of the batched shooting solver and their launchers (float path and everything that is not
+// the float64 search: igt_kernels_f64.hip holds that).
 //
-//   search_kernel   one wavefront per scenario: rolls all C candidates (NC per lane per pass),
-//                   cost + verdicts, lane-local best, 6-step wave butterfly arg-min,
-//                   writes (cost, argmin, status) = 12 B per solve.
-//   emit_kernel     one lane per scenario: re-rolls the winner with the same arithmetic and
-//                   writes x*[7,N+1], u*[2,N] (1/C of the search work).
-//   rollout_all_kernel   debug/parity: every candidate's trajectory, cost and verdict bits.
-//   cartesian_euler_kernel   kinematic_bicycle_model.py:15-50, one lane per trajectory.
+//   search_fast_kernel_*   persistent waves, one 128-candidate steering slice of one scenario per unit, two candidates per
+//                          lane as packed float pairs (igt_fast.h)
+//   emit_fast_kernel / emit_seg_kernel   the winner re-rolled (from checkpoints of the search pass for small batches)
+//   rollout_all_fast_kernel   debug / parity: every candidate's trajectory, cost and verdict bits
+//   reduce / refine kernels, the value-network launchers (igt_value_net.h), forecast_kernel, frenet_step kernels,
+//   cartesian_euler_kernel (kinematic_bicycle_model.py:15-50), first_controls_kernel (all-gather staging)
 #define IGT_KERNELS_TU 1
 #include "igt_device.h"
 #include "igt_fast.h"

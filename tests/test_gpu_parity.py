@@ -534,6 +534,37 @@ def test_value_net_with_ramp_hold_refinement_f64(igt, golden_dir):
     assert rel_err(got['cost'][sol], ref['cost'][sol]).max() < 1e-9
 
 
+@pytest.mark.parametrize('dtype,cand', [('f64', 'lattice'), ('f64', 'track'), ('f32', 'lattice'), ('f32', 'ramp_hold')])
+def test_cartesian_row_skip_changes_nothing(igt, dtype, cand, monkeypatch):
+    """Search units whose obstacles are out of every speed-feasible candidate's reach roll without x, y (igt_device.h
+    obstacles_out_of_reach; 70 % of the benchmark batch).  The switched-off build path (IGT_DEV_FLAGS = 65536) must give the
+    same solve bit for bit -- on the benchmark batch, on a batch whose obstacle sits just inside / just outside the reach
+    bound, and with two obstacles of which one is near."""
+    npdt = np.float64 if dtype == 'f64' else np.float32
+    b = _batch(1024, npdt)
+    far = (np.hypot(b['obs_xy'][:, 0, 0, 1:] - b['x0'][:, None, 0], b['obs_xy'][:, 0, 1, 1:] - b['x0'][:, None, 1]).min(axis=1) > 17.5)
+    assert 0.5 < far.mean() < 0.9                                  # both kinds of unit are exercised
+    # obstacles parked at the reach bound 5.6 + 20 * 0.1 * (5 + 4 * 0.1) + 1 = 17.4 m from the start, +- a little
+    edge = {k: v.copy() for k, v in b.items()}
+    ang = np.linspace(0, 2 * np.pi, 1024, endpoint=False)
+    r = 17.4 + np.tile(np.array([-0.5, -1e-6, 1e-6, 0.5]), 256)
+    edge['obs_xy'][:, 0, 0, :] = (b['x0'][:, 0] + r * np.cos(ang))[:, None]
+    edge['obs_xy'][:, 0, 1, :] = (b['x0'][:, 1] + r * np.sin(ang))[:, None]
+    two = {k: v[:256].copy() for k, v in b.items()}
+    two['obs_xy'] = np.concatenate([b['obs_xy'][:256], np.full_like(b['obs_xy'][:256], -20.0)], axis=1)
+    for batch, n_obs in ((b, 1), (edge, 1), (two, 2)):
+        outs = []
+        for flag in ('0', '65536'):
+            monkeypatch.setenv('IGT_DEV_FLAGS', flag)
+            with igt.BatchSolver(dtype=dtype, cand_mode=cand, n_obs=n_obs) as s:
+                s.set_cinf(*_cinf())
+                outs.append(s.solve(*_args(batch)))
+        monkeypatch.delenv('IGT_DEV_FLAGS')
+        assert (outs[0]['status'] == 0).any()
+        for k in ('x', 'u', 'cost', 'argmin', 'status'):
+            assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+
+
 @pytest.mark.parametrize('sc', [1, 3])
 def test_value_bound_pruning_changes_nothing(igt, golden_dir, sc, monkeypatch):
     """gt_mpc cost, tracking candidates (long lists of feasible candidates): the list is pruned with an interval bound on
