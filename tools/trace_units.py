@@ -20,6 +20,15 @@ with BatchSolver(dtype=DT) as s:
         s.solve(*args)
     torch.cuda.synchronize()
 tr = np.fromfile(path, dtype=np.uint64).reshape(-1, 4)
+if os.environ.get('IGT_TRACE_SAVE'):      # raw (scenario, slice, start, end) per unit, for offline analysis of the queue order
+    W = 4 if DT == 'f64' else 2
+    stride = ((B + 7) // 8) * W
+    row = np.arange(len(tr)); ok = tr[:, 1] > 0
+    qq = row // stride
+    jj = (tr[:, 3] >> 8).astype(np.int64)
+    bb = 8 * jj + ((qq - jj) & 7)
+    np.savez_compressed(os.environ['IGT_TRACE_SAVE'], b=bb[ok], p=(tr[ok, 3] & 255).astype(np.int64), t0=tr[ok, 0], t1=tr[ok, 1],
+                        wave=tr[ok, 2])
 tr = tr[tr[:, 1] > 0]
 t0 = tr[:, 0].astype(np.float64); t1 = tr[:, 1].astype(np.float64)
 base = t0.min(); t0 = (t0 - base) / 100.0; t1 = (t1 - base) / 100.0      # 100 MHz -> us
