@@ -4,6 +4,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -214,7 +215,9 @@ struct Arena {   // carves 256-byte aligned pieces out of the staging buffer
 
 // the queue builder of small float batches zeroes the search kernel's unit counters itself
 template <typename T>
-inline bool counters_by_builder(const igt::KP& kp, int B, const igt::SolveArgs<T>& A) { return igt::search_builds_queues(kp, B, A); }
+inline bool counters_by_builder(const igt::KP& kp, int B, const igt::SolveArgs<T>& A) {
+    return igt::search_is_static(kp, B, A) || igt::search_builds_queues(kp, B, A);      // ... or the search uses none
+}
 
 template <typename T>
 int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* kparams, const uint32_t* flags,
@@ -317,10 +320,18 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     }
     const bool use_ckpt = ck_parts > 1;
     const size_t ckpt_bytes = use_ckpt ? (size_t)(ck_parts - 1) * B * Wk * igt::SEG_UNIT_DOUBLES * 8 + 256 : 0;
+    // small double batches -- no more units than the chip has SIMDs, B <= 256 at 256 candidates -- : the search pass keeps
+    // every trajectory and emit copies the winner's (igt_kernels_common.h CaptureSink; 97 KB of stores per unit at N = 20,
+    // hidden behind a lone wave's dependent chains; with several units per SIMD they are not: a closed loop of 512
+    // problems per step ran 0.32 ms per step with them against 0.30 without, 0.43 against 0.36 at 1024)
+    size_t traj_max_units = (size_t)h->n_cu * 4;
+    if (const char* e = std::getenv("IGT_DEV_TRAJ_MAX")) traj_max_units = (size_t)std::min(std::max(std::atoi(e), 0), 8192) * Wk;   // sweeps: a batch size
+    const bool capture = sizeof(T) == 8 && !exact64 && (size_t)B * Wk <= traj_max_units && (p.C % 64) == 0;
+    const size_t traj_doubles = capture ? (size_t)B * Wk * igt::traj_unit_doubles(p.N) : 0;
     double* d_cpar = nullptr;
     {
         const size_t n_rec = value ? (size_t)B * p.C : 0;
-        const size_t need = (size_t)B * W * 12 + (size_t)B * 56 + 8192 + ckpt_bytes + (size_t)(B + 8) * Wk * 36 + 256 + n_rec * (2 * sizeof(T) + 16) +
+        const size_t need = traj_doubles * 8 + 256 + (size_t)B * W * 12 + (size_t)B * 56 + 8192 + ckpt_bytes + (size_t)(B + 8) * Wk * 36 + 256 + n_rec * (2 * sizeof(T) + 16) +
                             (value ? (size_t)B * igt::VN_H * sizeof(T) + (size_t)B * Wk * 8 + (size_t)B * 8 + n_rec * 4 + 512 : 0) + 20 * 256;
         if (int rc = ensure_work(h, need, st)) return rc;
         Arena wa{(char*)h->d_work, 0};
@@ -336,6 +347,7 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
         // small batches: the search queues are sorted longest unit first (build_queues_kernel; 3-5 % up to B = 4096,
         // nothing from 8192 on)
         A.queue_order = B <= 6144 ? wa.take<unsigned>((size_t)((B + 7) / 8) * 8 * Wk) : nullptr;
+        if constexpr (sizeof(T) == 8) A.traj = capture ? wa.take<double>(traj_doubles) : nullptr;
         if (value) {
             A.rec_J = wa.take<double>(n_rec);
             A.rec_sN = wa.take<T>(n_rec);

@@ -6,7 +6,8 @@
 //   * v and psi do not feed back: stage speeds and the psi offsets are closed-form;
 //   * sin/cos of (beta+epsi') and (psi'+beta) are rotations of the sub-step's base pair by the stage offset, the
 //     offset's sine / cosine from a Taylor polynomial (|offset| <= h |rate| << 1; truncation < 1e-17 relative);
-//     libm-grade sincos is evaluated once per control step (df, epsi) instead of 32 times;
+//     libm-grade sincos is evaluated once per control step (of the slip angle) instead of 32 times -- the (beta + epsi)
+//     and (psi + beta) pairs are carried from step to step by rotations and renormalised;
 //   * all weighted stage sums are factorised, sum_j w_j g_j cos(theta + d_j) = cos(theta) A - sin(theta) B, for the
 //     Frenet rows and the Cartesian rows (the latter including the reference's quirk that stage 4 sees
 //     psi + h/2 k3[6], kinematic_bicycle_model_frenet.py:111);

@@ -53,6 +53,24 @@ struct StoreSink {
     }
 };
 
+// Small batches: the search pass itself keeps every candidate's trajectory (unit-major, then field, step, lane: each store of
+// a wave is one 512-byte line), and emit copies the winner's instead of rolling it again -- the second roll is a serial chain
+// of N steps on one lane, 60 us of a 150 us solve at N = 20.  9 (N+1) 64 doubles per unit: 97 KB at N = 20, 400 MB of
+// stores at B = 1024 -- which is why this is for batches with at most one unit per SIMD only (igt_api.hip solve_impl).
+struct CaptureSink {
+    static constexpr bool kKeepsStates = true;
+    double* base;   // this unit's block + lane
+    int N1;         // N + 1
+    __device__ __forceinline__ void ctrl(int, int k, double a, double df) {
+        base[(size_t)(7 * N1 + k) * 64] = a;
+        base[(size_t)(8 * N1 + k) * 64] = df;
+    }
+    __device__ __forceinline__ void state(int, int k, const double (&st)[7]) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) base[(size_t)(i * N1 + k) * 64] = st[i];
+    }
+};
+
 // Scenario j of queue q.  Blocks of 8 consecutive scenarios are dealt to the 8 queues rotated by the block index, so
 // that a batch whose make-up repeats with a period of 8 (the benchmark's does: route pair and ego index are functions
 // of b mod 64) does not give one XCD all the turning routes: measured 30 % spread between the queues' finishing times

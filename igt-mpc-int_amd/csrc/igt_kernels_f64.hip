@@ -181,7 +181,7 @@ __device__ __forceinline__ int slice_candidate64(const KP& P, int W, int p, int 
 
 // One work unit = one (scenario, 64-candidate slice), rolled by one wave; leaves the slice's best (J, c), or -- value-net
 // cost -- every candidate's record for value_kernel<double> (mpc.py:369).
-template <int CAND, bool HI, bool VALUE, int NRK = 0>
+template <int CAND, bool HI, bool VALUE, int NRK = 0, bool CAPTURE = false>
 __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, const double* __restrict__ x0,
                                               const double* __restrict__ u_prev, const double* __restrict__ kparams,
                                               const uint32_t* __restrict__ flags, const double* __restrict__ obs,
@@ -190,7 +190,8 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
                                               int32_t* __restrict__ part_c, double* __restrict__ rec_sN,
                                               double* __restrict__ rec_vN, double* __restrict__ rec_J,
                                               uint32_t* __restrict__ rec_viol, unsigned* __restrict__ rec_count,
-                                              int32_t* __restrict__ rec_b, int2* __restrict__ unit_seg) {
+                                              int32_t* __restrict__ rec_b, int2* __restrict__ unit_seg,
+                                              double* __restrict__ traj = nullptr) {
     const int lane = threadIdx.x & 63;
     Scenario<double> S;
     load_scenario<double>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
@@ -198,6 +199,21 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
     const int c = slice_candidate64<CAND>(P, W, p, lane);
     double J, sN, vN;
     unsigned viol;
+    if constexpr (CAPTURE) {      // small batches: every lane's trajectory is kept for emit_gather_f64_kernel (all rows, so no
+                                  // Cartesian skip; same arithmetic as below, same bits)
+        CaptureSink keep{traj + (size_t)(b * W + p) * traj_unit_doubles(P.N) + lane, P.N + 1};
+        constexpr bool TAB = CAND == CAND_LATTICE || CAND == CAND_RAMP_HOLD;
+        const int njc = P.G / W;
+        if (TAB && steering_slices64<CAND>(P, W) && njc * P.N <= f64::STAB_MAX_ENTRIES && !(P.dev & 4)) {
+            __shared__ double stabc[f64::STAB_MAX_ENTRIES * 3];
+            f64::fill_steer_table<CAND>(P, S, njc, p, lane, P.lr_ratio, stabc);
+            f64::rollout_one<CAND, HI, true, true, CaptureSink, true, true, NRK, true>(P, S, c, table, cinf, keep, J, viol, sN, vN,
+                                                                                       stabc + (lane % njc) * 3, njc * 3);
+            __syncthreads();
+        } else {
+            f64::rollout_one<CAND, HI, true, true, CaptureSink, true, false, NRK, true>(P, S, c, table, cinf, keep, J, viol, sN, vN);
+        }
+    } else {
     // steering slices of the families with state-independent steering: the slice's G/W steering columns are laid out in
     // LDS once per unit instead of being recomputed by each of their 64 W/G lanes at every step (igt_fast64.h)
     constexpr bool TABULATED = CAND == CAND_LATTICE || CAND == CAND_RAMP_HOLD;
@@ -219,6 +235,7 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
         f64::rollout_one<CAND, HI, true, true, NullSink, true, false, NRK, false>(P, S, c, table, cinf, sink, J, viol, sN, vN);
     } else {
         f64::rollout_one<CAND, HI, true, true, NullSink, true, false, NRK, true>(P, S, c, table, cinf, sink, J, viol, sN, vN);
+    }
     }
     if (VALUE) {   // terminal value network (mpc.py:369): append the feasible candidates for value_mfma_f64_kernel; the
                    // unit's entries are contiguous, unit_seg remembers where (unit_reduce_kernel picks the unit's best)
@@ -264,6 +281,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         search_unit64<CAND, HI, VALUE, NRK>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN,
                                        rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg);
     });
+}
+// small batches (captures_trajectories): the same search, every unit also leaves its 64 trajectories in `traj`
+template <int CAND, bool VALUE>
+__global__ __launch_bounds__(64) void search_f64_kernel_cap(IGT_SEARCH64_ARGS, double* __restrict__ traj) {
+    if (queues == 0) {      // every unit has a wave of its own (search_is_static): no queues, no counters
+        search_unit64<CAND, false, VALUE, 4, true>(P, W, (int)(blockIdx.x / (unsigned)W), (int)(blockIdx.x % (unsigned)W), x0, u_prev,
+                                                   kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN, rec_vN, rec_J,
+                                                   rec_viol, rec_count, rec_b, unit_seg, traj);
+        return;
+    }
+    search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
+        search_unit64<CAND, false, VALUE, 4, true>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c,
+                                                   rec_sN, rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg, traj);
+    });
+}
+// one 64-thread block per scenario: final arg-min over the W partials, then the winner's trajectory copied out of the unit
+// that rolled it.  Which lane that was is asked of slice_candidate64 itself, so the two cannot drift apart.
+template <int CAND>
+__global__ __launch_bounds__(64) void emit_gather_f64_kernel(KP P, int B, int W, const double* __restrict__ part_J,
+                                                             const int32_t* __restrict__ part_c,
+                                                             const double* __restrict__ traj, double* __restrict__ cost_out,
+                                                             int32_t* __restrict__ argmin_out, int32_t* __restrict__ status_out,
+                                                             double* __restrict__ x_out, double* __restrict__ u_out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double bestJ = 0.0;
+    int c = -1, pw = 0;
+    for (int w = 0; w < W; ++w) {      // (J, c) lexicographic, as emit_f64_kernel
+        const int cw = part_c[(size_t)b * W + w];
+        const double Jw = part_J[(size_t)b * W + w];
+        if (cw >= 0 && (c < 0 || Jw < bestJ || (Jw == bestJ && cw < c))) { bestJ = Jw; c = cw; pw = w; }
+    }
+    if (lane == 0) {
+        cost_out[b] = c >= 0 ? bestJ : (double)INFINITY;
+        argmin_out[b] = c;
+        status_out[b] = c >= 0 ? 0 : 1;
+    }
+    const int N1 = P.N + 1, nx = 7 * N1, nu = 2 * P.N;
+    double* xo = x_out + (size_t)b * nx;
+    double* uo = u_out + (size_t)b * nu;
+    const unsigned long long holder = __ballot(c >= 0 && slice_candidate64<CAND>(P, W, pw, lane) == c);
+    if (c < 0 || holder == 0ull) {     // is_opt False (mpc.py:402-406): no trajectory
+        for (int i = lane; i < nx; i += 64) xo[i] = (double)NAN;
+        for (int i = lane; i < nu; i += 64) uo[i] = (double)NAN;
+        return;
+    }
+    const double* src = traj + (size_t)(b * W + pw) * traj_unit_doubles(P.N) + (__ffsll((long long)holder) - 1);
+    for (int i = lane; i < nx; i += 64) xo[i] = src[(size_t)i * 64];
+    for (int i = lane; i < nu; i += 64) uo[i] = src[(size_t)((7 + i / P.N) * N1 + i % P.N) * 64];
 }
 #if IGT_DEV_KERNELS
 template <int CAND, bool HI, bool VALUE>
@@ -464,6 +529,20 @@ bool search_builds_queues(const KP& P, int B, const SolveArgs<double>& A) {
     return A.queue_order && W <= 256 && ((B + 7) / 8) * W <= QB_THREADS * QB_TRIPS && !(P.dev & 16) && !(P.dev & (1024 | 2048));
 }
 
+// Small batches keep the trajectories of the search pass (CaptureSink) when the kernel built for the reference's
+// discretisation runs; IGT_DEV_FLAGS = 524288 switches it off for A/B runs.
+static bool captures_trajectories(const KP& P, const SolveArgs<double>& A) {
+    return A.traj && !P.hi_order && P.n_rk4 == 4 && !(P.dev & (32 | 1024 | 2048 | 524288));
+}
+
+// ... and such a batch has no more units than the chip has SIMDs (the kernel that keeps trajectories holds one wave per
+// SIMD), so every unit is given its own wave: the queue builder (6.6 us and a launch) would only order units that all start
+// at once.  Measured, search + emit, tracking family: 67 us against 84 at B = 1, 91 against 101 at B = 32.
+// IGT_DEV_FLAGS = 1048576 keeps the queues for A/B runs; the unit trace (256) needs them.
+bool search_is_static(const KP& P, int B, const SolveArgs<double>& A) {
+    return captures_trajectories(P, A) && (size_t)B * (P.C / 64) <= (size_t)A.n_cu * 4 && !(P.dev & (256 | 1048576));
+}
+
 // float64 search: persistent waves on the per-XCD queues, one 64-candidate unit at a time
 template <int CAND, bool HI, bool VALUE>
 static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A, hipStream_t st) {
@@ -483,10 +562,22 @@ static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A
     const size_t grid = total < slots ? total : slots;
     const unsigned* order = nullptr;
     const int order_stride = ((B + 7) / 8) * W;
+    if (!HI && search_is_static(P, B, A)) {
+        hipLaunchKernelGGL((search_f64_kernel_cap<CAND, VALUE>), dim3(total), dim3(64), 0, st, P, B, W, 0, A.work_counter, order,
+                           order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c,
+                           A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b, A.unit_seg, A.traj);
+        return hipGetLastError();
+    }
     if (search_builds_queues(P, B, A)) {                     // small batches: longest units first
         hipLaunchKernelGGL(build_queues_kernel<double>, dim3(8), dim3(QB_THREADS), 0, st, P, B, W, A.x0, A.kparams,
                            A.queue_order, order_stride, A.work_counter);
         order = A.queue_order;
+    }
+    if (!HI && captures_trajectories(P, A)) {
+        hipLaunchKernelGGL((search_f64_kernel_cap<CAND, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter, order,
+                           order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c,
+                           A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b, A.unit_seg, A.traj);
+        return hipGetLastError();
     }
 #if IGT_DEV_KERNELS
     if (o3)
@@ -540,6 +631,11 @@ hipError_t launch_search_records<double>(const KP& P, int B, const SolveArgs<dou
 template <int CAND, bool HI>
 static hipError_t launch_emit64(const KP& P, int B, int W, const SolveArgs<double>& A, hipStream_t st) {
     constexpr int NRK4 = HI ? 0 : 4;
+    if (!HI && captures_trajectories(P, A)) {
+        hipLaunchKernelGGL((emit_gather_f64_kernel<CAND>), dim3(B), dim3(64), 0, st, P, B, W, A.part_J, A.part_c, A.traj, A.cost_out,
+                           A.argmin_out, A.status_out, A.x_out, A.u_out);
+        return hipGetLastError();
+    }
     if (NRK4 == 4 && P.n_rk4 == 4)
         hipLaunchKernelGGL((emit_f64_kernel<CAND, HI, NRK4>), dim3((B + 63) / 64), dim3(64), 0, st, P, B, W, A.x0, A.u_prev, A.kparams,
                            A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, A.cost_out, A.argmin_out, A.status_out,

@@ -7,6 +7,10 @@
 
 namespace igt {
 
+// trajectories kept by the search pass of a small double batch (igt_kernels_common.h CaptureSink)
+constexpr int TRAJ_FIELDS = 9;                    // the 7 states, then a and delta_f
+__host__ __device__ inline size_t traj_unit_doubles(int N) { return (size_t)TRAJ_FIELDS * (N + 1) * 64; }
+
 template <typename T>
 struct SolveArgs {   // all device pointers
     const T* x0;
@@ -46,10 +50,13 @@ struct SolveArgs {   // all device pointers
     int2* unit_seg;                 // double path: [B, C/64] (first entry, count) of each unit's entries in the compact list
     double* prune_thr;              // double path: [B] cost above which an entry cannot win (value_bound_kernel)
     unsigned* live_idx;             // double path: entries left for the network after value_prune_kernel
+    double* traj;                   // double path, small batches: [B C/64][9][N+1][64] kept by the search pass (null: none)
 };
 
 bool search_builds_queues(const KP& P, int B, const SolveArgs<float>& A);   // then no memset of the counters is needed
 bool search_builds_queues(const KP& P, int B, const SolveArgs<double>& A);
+bool search_is_static(const KP& P, int B, const SolveArgs<double>& A);      // one wave per unit: no queues, no counters
+inline bool search_is_static(const KP&, int, const SolveArgs<float>&) { return false; }
 template <typename T> hipError_t launch_search(const KP& P, int B, const SolveArgs<T>& A, int nc, hipStream_t st);
 template <typename T> hipError_t launch_emit(const KP& P, int B, int W, const SolveArgs<T>& A, hipStream_t st);
 // value-net cost: search pass that writes per-candidate records, then prep + MLP + per-chunk arg-min

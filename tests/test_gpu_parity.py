@@ -555,6 +555,61 @@ def test_production_kernel_switches_change_nothing(igt, dtype, cand, monkeypatch
             assert np.array_equal(o[k], outs[0][k], equal_nan=True), (flag, k)
 
 
+@pytest.mark.parametrize('cand,N', [('lattice', 20), ('track', 20), ('ramp_hold', 20), ('track', 40), ('table', 20)])
+def test_kept_trajectories_are_the_rerolled_ones(igt, cand, N, monkeypatch):
+    """Double batches with no more 64-candidate units than the chip has SIMDs (256 scenarios at 256 candidates): the search
+    pass keeps every candidate's trajectory and emit copies the winner's (igt_kernels_common.h CaptureSink,
+    emit_gather_f64_kernel) instead of rolling it again.  With the capture switched off (IGT_DEV_FLAGS = 524288:
+    emit_f64_kernel re-rolls) the solve is the same bit for bit -- at B = 1, 33 (ragged last block of 8) and 256, for every
+    candidate family, at both horizons.  Every unit of such a batch gets a wave of its own instead of a place in the XCDs'
+    queues (search_is_static; IGT_DEV_FLAGS = 1048576 keeps the queues): same bits again."""
+    rng = np.random.default_rng(5)
+    table = None
+    if cand == 'table':
+        a, d = np.meshgrid(np.linspace(-0.25, 0.25, 16), np.linspace(-0.04, 0.04, 16), indexing='ij')     # held controls
+        table = np.ascontiguousarray(np.stack([a.ravel(), d.ravel()], axis=1)[:, :, None] * np.ones(N) +
+                                     1e-3 * rng.normal(size=(256, 2, N)))
+    full = _batch(256, np.float64, N=N)
+    for B in (1, 33, 256):
+        b = {k: np.ascontiguousarray(v[:B]) for k, v in full.items()}
+        outs = []
+        for flag in ('0', '524288', '1048576'):      # default; re-rolled by emit; kept, but with the unit queues
+            monkeypatch.setenv('IGT_DEV_FLAGS', flag)
+            with igt.BatchSolver(N=N, dtype='f64', cand_mode=cand) as s:
+                s.set_cinf(*_cinf())
+                if table is not None:
+                    s.set_candidate_table(table)
+                outs.append(s.solve(*_args(b)))
+        monkeypatch.delenv('IGT_DEV_FLAGS')
+        if B == 256:
+            assert (outs[0]['status'] == 0).mean() > 0.1
+        for k in ('x', 'u', 'cost', 'argmin', 'status'):
+            assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), (B, k)
+            assert np.array_equal(outs[0][k], outs[2][k], equal_nan=True), (B, k)
+
+
+@pytest.mark.parametrize('cost_mode,refine', [('value_net', 0), ('progress', 2)])
+def test_kept_trajectories_with_value_net_and_refinement(igt, golden_dir, cost_mode, refine, monkeypatch):
+    """Same as above where the winner is not the search pass's own: chosen by the terminal value network after the pass
+    (gt_mpc), or by the last of three ramp-hold passes (each pass overwrites the kept trajectories)."""
+    b = _batch(200, np.float64)
+    cand = 'track' if cost_mode == 'value_net' else 'ramp_hold'
+    outs = []
+    for flag in ('0', '524288'):
+        monkeypatch.setenv('IGT_DEV_FLAGS', flag)
+        with igt.BatchSolver(dtype='f64', cost_mode=cost_mode, cand_mode=cand, refine_iters=refine) as s:
+            s.set_cinf(*_cinf())
+            if cost_mode == 'value_net':
+                s.set_value_net(layers=_nets(golden_dir)[3], Wn=np.eye(6), mu_f=np.zeros(6), sigma_t=1.0, mu_t=0.0)
+                outs.append(s.solve(*_args(b), b['tv_sv'], b['enc']))
+            else:
+                outs.append(s.solve(*_args(b)))
+    monkeypatch.delenv('IGT_DEV_FLAGS')
+    assert (outs[0]['status'] == 0).mean() > 0.5
+    for k in ('x', 'u', 'cost', 'argmin', 'status'):
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+
+
 @pytest.mark.parametrize('dtype,cand', [('f64', 'lattice'), ('f64', 'track'), ('f32', 'lattice'), ('f32', 'ramp_hold')])
 def test_cartesian_row_skip_changes_nothing(igt, dtype, cand, monkeypatch):
     """Search units whose obstacles are out of every speed-feasible candidate's reach roll without x, y (igt_device.h

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer probe (GPU box): latency of ONE solve at the batch sizes a per-agent caller has (B = 1, 2, 32), host buffers
 (numpy in / numpy out, what MPC_Planner.solve does) and device buffers, tracking candidates, f64.
-    python tools/latency_probe.py"""
+    python tools/latency_probe.py [B ...]        IGT_DEV_FLAGS=524288: without the trajectories kept by the search pass"""
 import os
 import sys
 import time
@@ -16,8 +16,9 @@ from igtmpc import BatchSolver  # noqa: E402
 from igtmpc.cinf import cinf_halfplanes  # noqa: E402
 from igtmpc.scenarios import make_batch  # noqa: E402
 
+BATCHES = [int(a) for a in sys.argv[1:]] or [1, 2, 32]
 for N in (20, 40):
-    for B in (1, 2, 32):
+    for B in BATCHES:
         b = make_batch(max(B, 8), N=N, dtype=np.float64)
         host = [np.ascontiguousarray(b[k][:B]) for k in ('x0', 'u_prev', 'kparams', 'flags', 'obs_xy')]
         dev = [torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda() for a in host]
