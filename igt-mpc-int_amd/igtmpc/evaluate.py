@@ -18,6 +18,7 @@ Not kept: pickles / CSV / mp4 output, the unseeded route shuffle (routes are sor
 """
 import argparse
 import json
+import os
 import time
 
 import numpy as np
@@ -31,7 +32,7 @@ from .value_nets import shipped_value_net
 A_MIN_POLICY = -4.0        # mpc.yaml:8, used by the brake fallback (evaluate.py:514)
 
 
-def initial_states(rng, route_pairs):
+def initial_states(rng, route_pairs, v0=0.0):
     """evaluate.py:91-94 + 404-418: every episode draws one offset per approach lane (order 1,2,3,4);
     an agent starting at origin o sits `offset_o` metres down its lane with v = 0, ey = epsi = 0."""
     E = len(route_pairs)
@@ -46,7 +47,7 @@ def initial_states(rng, route_pairs):
             s0 = off[e, int(r[0]) - 1]
             xy = R.frenet2global(rid[e, m], s0)
             h0 = {'1': 0.0, '2': -np.pi / 2, '3': -np.pi, '4': np.pi / 2}[r[0]]     # evaluate.py:58-61
-            x[e, m] = (xy[0], xy[1], s0, 0.0, 0.0, 0.0, h0)
+            x[e, m] = (xy[0], xy[1], s0, 0.0, 0.0, v0, h0)                          # fourwayint.yaml:11 v0
     return x, rid
 
 
@@ -63,7 +64,8 @@ def auto_track_env(N, dt):
 def run_closed_loop(sc=1, num_samples=1, N=40, dt=0.1, T_sim=15.0, seed=2026, C=256, n_rk4=4, device=0,
                     dtype='f64', rotation=None, cand_mode='track', refine_iters=0, verbose=False,
                     eval_mode='mpc', value_net=None, device_resident=False, warm_start=True, init=None,
-                    terminal_set=True, feas_tol=None, limits=None, graph=False):
+                    terminal_set=True, feas_tol=None, limits=None, graph=False, a_min_policy=None, constant_speed=False,
+                    v0=0.0):
     """eval_mode 'mpc' (evaluate.py:370-639) or 'gt_mpc' (123-369: terminal value network in the cost;
     value_net = dict(layers=[(W,b),...][, Wn, mu_f, sigma_t, mu_t]), default: the network the reference ships for
     scenario sc -- its normalisation statistics are not shipped, identity unless given).  device_resident=True keeps every per-step array in HBM (torch tensors;
@@ -74,7 +76,11 @@ def run_closed_loop(sc=1, num_samples=1, N=40, dt=0.1, T_sim=15.0, seed=2026, C=
     constraint (mpc.py:177-180) -- a test switch.  feas_tol: inequality tolerance of the verdicts (default: the
     library's 1e-6; IPOPT's constr_viol_tol is 1e-3, mpc.py:135); limits: further igt_params fields by name
     (e.g. dict(track_env=0.0); without it the tracking family's envelope scale follows the horizon: auto_track_env).
-    graph=True (with device_resident): the time loop replays one captured step."""
+    graph=True (with device_resident): the time loop replays one captured step.
+    a_min_policy: deceleration of the brake fallback (mpc.yaml:8 a_min through evaluate.py:514; default -4);
+    constant_speed: the forecast holds the other agent's speed (mpc.yaml:13-14 prediction_type, evaluate.py:76-79);
+    v0: initial speed (fourwayint.yaml:11) -- load_reference_configs reads all three from the reference's files."""
+    a_min_policy = A_MIN_POLICY if a_min_policy is None else float(a_min_policy)
     gt = eval_mode == 'gt_mpc'
     if gt and value_net is None:
         if init is not None:
@@ -90,7 +96,7 @@ def run_closed_loop(sc=1, num_samples=1, N=40, dt=0.1, T_sim=15.0, seed=2026, C=
     else:
         E = num_samples
         pairs = [R.SCENARIO_ROUTES[sc - 1][(e if rotation is None else rotation) % 4] for e in range(E)]
-        x, rid = initial_states(rng, pairs)                             # x[E,M,7]
+        x, rid = initial_states(rng, pairs, v0=v0)                      # x[E,M,7]
     warm = bool(warm_start) and cand_mode in ('ramp_hold', 'track')
     limits = dict(limits or {})
     if cand_mode == 'track' and 'track_env' not in limits:
@@ -114,12 +120,13 @@ def run_closed_loop(sc=1, num_samples=1, N=40, dt=0.1, T_sim=15.0, seed=2026, C=
         enc = enc.reshape(E * M, 2)
     if terminal_set:
         solver.set_cinf(*cinf_halfplanes(dt=dt, jerk=solver.params.jerk_limit))
-    stepper = BatchSolver(N=1, dt=dt, n_rk4=n_rk4, C=64, n_obs=0, device=device, dtype='f64')
+    stepper = BatchSolver(N=1, dt=dt, n_rk4=n_rk4, C=64, n_obs=0, device=device, dtype='f64',
+                          **{k: v for k, v in limits.items() if k in ('l_r', 'l_f')})      # the same vehicle
     npdt = solver.np_dtype
 
     if device_resident:
         out = _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc if gt else None, gt, E, M, N, M_sim, device, warm,
-                           graph=graph)
+                           graph=graph, a_min_policy=a_min_policy, constant_speed=constant_speed)
         solver.close()
         stepper.close()
         out['routes'] = pairs
@@ -144,6 +151,8 @@ def run_closed_loop(sc=1, num_samples=1, N=40, dt=0.1, T_sim=15.0, seed=2026, C=
         a_fc = u_prev[:, other, 0]
         if gt and t == 0:                                               # evaluate.py:207-210: a = 0.09 (k+1) for agent k
             a_fc = np.tile(0.09 * (np.arange(M)[::-1] + 1.0), (E, 1))
+        if constant_speed:                                              # constant_acceleration_model.py:26-29
+            a_fc = np.zeros((E, M))
         obs, tv = solver.forecast(ego_xyh.astype(npdt), opp.astype(npdt), a_fc.reshape(-1).astype(npdt),
                                    rid[:, other].reshape(-1).astype(np.int32),
                                    sol_x[:, other].reshape(E * M, 7, N + 1).astype(npdt),
@@ -165,7 +174,7 @@ def run_closed_loop(sc=1, num_samples=1, N=40, dt=0.1, T_sim=15.0, seed=2026, C=
         us = out['u'].reshape(E, M, 2, N).astype(np.float64)
         # --- infeasible: brake fallback (evaluate.py:511-545)
         v_now = x[..., 5]
-        a_fb = np.where(v_now > 0, A_MIN_POLICY, 0.0)
+        a_fb = np.where(v_now > 0, a_min_policy, 0.0)
         u_fb = np.stack([a_fb, u_prev[..., 1]], axis=-1)
         nxt_fb = stepper.frenet_step(x.reshape(E * M, 7), u_fb.reshape(E * M, 2), kp.reshape(E * M, 3)).reshape(E, M, 7)
         neg = v_now < 0                                                 # evaluate.py:523-526: instantaneous stop
@@ -198,7 +207,8 @@ def shift_controls(u):
     return torch.cat([u[..., 1:], u[..., -1:]], dim=-1)
 
 
-def _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc, gt, E, M, N, M_sim, device, warm, graph=False):
+def _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc, gt, E, M, N, M_sim, device, warm, graph=False,
+                 a_min_policy=A_MIN_POLICY, constant_speed=False):
     """The same time loop with every array resident in HBM (float64 state, solver-dtype views per call).
     graph=True: steps 0 and 1 run eagerly, then ONE step -- forecast, solve, fallback step and the ~40 small tensor
     operations between them -- is captured in a stream graph and replayed for the remaining steps (the state lives in
@@ -229,6 +239,8 @@ def _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc, gt, E, M, N, M
     def step(first, warm_ok=True):
         xo, uo = x.flip(1), u_prev.flip(1)
         a_fc = a_fc0 if (gt and first) else uo[..., 0]
+        if constant_speed:
+            a_fc = torch.zeros_like(uo[..., 0])
         hp = (have_sol.flip(1) & (not first)).reshape(-1).to(torch.int32).contiguous()
         obs, tv = solver.forecast(x.index_select(2, ix).reshape(E * M, 3).to(td).contiguous(),
                                   xo.index_select(2, io).reshape(E * M, 4).to(td).contiguous(),
@@ -245,7 +257,7 @@ def _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc, gt, E, M, N, M
         xs = out['x'].reshape(E, M, 7, N + 1)
         us = out['u'].reshape(E, M, 2, N)
         v_now = x[..., 5]
-        a_fb = torch.where(v_now > 0, torch.full_like(v_now, A_MIN_POLICY), torch.zeros_like(v_now))
+        a_fb = torch.where(v_now > 0, torch.full_like(v_now, a_min_policy), torch.zeros_like(v_now))
         neg = v_now < 0
         u_fb = torch.stack([torch.where(neg, torch.zeros_like(a_fb), a_fb), u_prev[..., 1]], dim=-1)
         u_step = torch.stack([a_fb, u_prev[..., 1]], dim=-1)
@@ -297,11 +309,128 @@ def _loop_device(solver, stepper, x, u_prev, kp, flags, rid, enc, gt, E, M, N, M
                 wall_s=wall)
 
 
+def load_reference_configs(policy_yaml=None, env_yaml=None):
+    """The reference driver's two configuration files -- mpc.yaml (evaluate.py:32-33) and common/fourwayint.yaml
+    (evaluate.py:28-29) -- as keyword arguments of run_closed_loop: -> (kwargs, policy) where `policy` is the parsed
+    mpc.yaml (what save_results writes back, evaluate.py:327-329).  What the driver reads of them is honoured
+    (N, dt, a_min of the brake fallback, prediction_type, v0, ca_radius, l_r, l_f); what this package holds as frozen,
+    reference-generated tables is CHECKED and refused when it differs (road geometry and fillet radius behind
+    igtmpc/data/route_constants.json, the forecast's speed clip, two agents, the circle constraint) -- a silent mismatch
+    would be a different intersection."""
+    import yaml
+    kw, policy = {}, {}
+    if policy_yaml is not None:
+        with open(policy_yaml) as f:
+            policy = yaml.safe_load(f) or {}
+        if policy.get('type', 'MPC') != 'MPC':
+            raise ValueError(f"{policy_yaml}: type {policy.get('type')!r} -- only 'MPC' is a policy here (evaluate.py:69)")
+        if policy.get('collision_avoidance_type', 'circle') != 'circle':
+            raise ValueError(f"{policy_yaml}: collision_avoidance_type {policy['collision_avoidance_type']!r} -- only the circle "
+                             'constraint (mpc.py:223-226) is implemented')
+        pt = str(policy.get('prediction_type', 'constant_acceleration'))
+        if 'constant_acceleration' in pt:                                  # evaluate.py:76-81, in the reference's order
+            kw['constant_speed'] = False
+        elif 'constant_speed' in pt:
+            kw['constant_speed'] = True
+        else:
+            raise ValueError('Invalid prediction type')
+        if 'N' in policy:
+            kw['N'] = int(policy['N'])
+        if 'a_min' in policy:
+            kw['a_min_policy'] = float(policy['a_min'])
+    if env_yaml is not None:
+        with open(env_yaml) as f:
+            env = yaml.safe_load(f) or {}
+        frozen = {'road_width': R.ROAD_WIDTH, 'road_length': R.ROAD_LENGTH, 'ca_radius': R.CA_RADIUS, 'num_agents': 2,
+                  'v_max': 20.0, 'v_min': -2.0}
+        for k, want in frozen.items():
+            if k in env and abs(float(env[k]) - want) > 1e-12:
+                raise ValueError(f'{env_yaml}: {k} = {env[k]} but the route tables / forecast of this package were generated for '
+                                 f'{want} (igtmpc/data/route_constants.json, tests/golden/make_golden.py)')
+        if 'dt' in env:
+            kw['dt'] = float(env['dt'])
+        if 'v0' in env:
+            kw['v0'] = float(env['v0'])
+        lim = {k: float(env[k]) for k in ('l_r', 'l_f') if k in env}
+        if lim:
+            kw['limits'] = lim
+    if 'dt' in policy and 'dt' in kw and abs(float(policy['dt']) - kw['dt']) > 1e-12:
+        raise ValueError(f"mpc.yaml dt = {policy['dt']} and fourwayint.yaml dt = {kw['dt']} disagree")
+    return kw, policy
+
+
+def save_results(r, save_dir, eval_mode, sc, seed=2026, policy=None, timenow=None):
+    """The run directory the reference's driver leaves behind (evaluate.py:319-369 gt_mpc, 578-640 mpc), from the result of
+    run_closed_loop -- so that what reads the reference's runs (generate_video.py:180-191 takes cl_traj.pkl[index] as
+    [7 M, T+1] rows x, y, s, ey, epsi, v, heading per agent) reads these:
+
+        <save_dir><eval_mode>_sc<sc>_seed<seed>_<time>/mpc/                  cl_traj.pkl [E, 7M, T+1], u_cl.pkl [E, 2M, T],
+                                                                             eval_stats.csv, evaluation_data.pkl, mpc.yaml
+        <save_dir><eval_mode>_sc<sc>_seed<seed>_<time>/game_mpc/evaluation/  cl_traj.pkl, u_cl.pkl, stats.csv, mpc.yaml
+
+    `save_dir` is joined the way the reference joins it (plain concatenation: give it a trailing separator).  One csv row per
+    episode with the reference's columns; the solve-time columns hold the lock-step batch's step time in seconds for every
+    agent (the reference sums IPOPT's t_* statistics per agent, evaluate.py:294-297), its standard deviation over the steps
+    (the reference's mpc branch takes the std of the mean, i.e. 0 -- evaluate.py:604).  Not written: the .mp4 (the directory is made) and the `refs`
+    entry of evaluation_data.pkl (ReferenceGen's Euler-rolled path arrays, a set-up-time product outside this package).
+    -> the run directory."""
+    import csv
+    import datetime
+    import pickle
+
+    import yaml
+    gt = eval_mode == 'gt_mpc'
+    timenow = timenow or datetime.datetime.now().strftime('%Y%m%d_%H%M%S')                     # evaluate.py:66
+    run = save_dir + eval_mode + '_sc' + str(sc) + '_seed' + str(seed) + '_' + timenow
+    out = run + ('/game_mpc/evaluation' if gt else '/mpc')
+    os.makedirs(out, exist_ok=True)
+    os.makedirs(run + ('/game_mpc/evaluation_videos' if gt else '/mpc/evaluation_videos'), exist_ok=True)
+    x_cl, u_cl = np.asarray(r['x_data']), np.asarray(r['u_data'])
+    E, M = x_cl.shape[0], x_cl.shape[1] // 7
+    with open(out + '/mpc.yaml', 'w') as f:
+        yaml.safe_dump(dict(policy or {}), f)
+    for name, arr in (('cl_traj.pkl', x_cl), ('u_cl.pkl', u_cl)):
+        path = out + '/' + name
+        if os.path.isfile(path):                                                               # evaluate.py:341-350: runs append
+            with open(path, 'rb') as f:
+                arr = np.concatenate([pickle.load(f), arr], axis=0)
+        with open(path, 'wb') as f:
+            pickle.dump(arr, f)
+    step_s = np.asarray(r['solve_ms'], dtype=np.float64) / 1e3
+    rows = []
+    for e in range(E):
+        row = {'avg_sol_times': np.full(M, step_s.mean()), 'std_solve_times': [float(step_s.std())] * M,
+               'infeasible_ratio': np.asarray(r['infeasible_ratio'][e]), 'deadlock': bool(r['deadlock'][e])}
+        rows.append(dict({'NN_query_time': np.array([-1])}, **row) if gt else row)               # evaluate.py:355, 605
+    csv_file = out + ('/stats.csv' if gt else '/eval_stats.csv')
+    fresh = not os.path.isfile(csv_file)
+    with open(csv_file, mode='w' if fresh else 'a', newline='') as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        if fresh:
+            w.writeheader()
+        w.writerows(rows)
+    if not gt:                                                                                 # evaluate.py:592-602
+        data = {'N': (policy or {}).get('N'), 'x_cl': x_cl, 'u_cl': u_cl, 'agent_types': ['CAV'] * M, 'weights': np.ones((E, 2)),
+                'routes': np.array([list(p) for p in r['routes']]), 'deadlock': np.asarray(r['deadlock']).reshape(E, 1),
+                'initial_agents': x_cl[:, :, 0].reshape(E, M, 7)}
+        path = out + '/evaluation_data.pkl'
+        if os.path.isfile(path):
+            with open(path, 'rb') as f:
+                old = pickle.load(f)
+            for k in ('x_cl', 'u_cl', 'weights', 'routes', 'deadlock', 'initial_agents'):
+                data[k] = np.concatenate([old[k], data[k]], axis=0)
+        with open(path, 'wb') as f:
+            pickle.dump(data, f, protocol=pickle.HIGHEST_PROTOCOL)
+    return run
+
+
 def main():
     ap = argparse.ArgumentParser(description='batched closed-loop evaluation (counterpart of evaluate.py --eval_mode mpc)')
     ap.add_argument('--sc', type=int, default=1)
     ap.add_argument('--num_samples', type=int, default=1)
-    ap.add_argument('--N', type=int, default=40, help='horizon; mpc.yaml:6 ships 40 (BASELINE.json benchmarks 20)')
+    ap.add_argument('--N', type=int, default=None, help='horizon; default: the policy file\'s, else 40 (mpc.yaml:6; BASELINE.json benchmarks 20)')
+    ap.add_argument('--policy_config', default=None, help="the reference's mpc.yaml (evaluate.py:32)")
+    ap.add_argument('--env_config', default=None, help="the reference's common/fourwayint.yaml (evaluate.py:28)")
     ap.add_argument('--C', type=int, default=256)
     ap.add_argument('--eval_mode', default='mpc', choices=['mpc', 'gt_mpc'])
     ap.add_argument('--value_net', default=None, help='gt_mpc: .npz with W0,b0,W1,b1,... (optionally prefixed, see --net_prefix); '
@@ -312,6 +441,8 @@ def main():
     ap.add_argument('--graph', action='store_true', help='with --device_resident: capture one step in a stream graph and replay it')
     ap.add_argument('--cand_mode', default='track', choices=['lattice', 'ramp_hold', 'track'])
     ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
+    ap.add_argument('--save_dir', default=None, help='write the run directory the reference\'s driver writes (cl_traj.pkl, u_cl.pkl, '
+                    'stats csv, mpc.yaml; evaluate.py:646) under <save_dir><eval_mode>_sc<sc>_seed2026_<time>/')
     a = ap.parse_args()
     net = None
     if a.eval_mode == 'gt_mpc':
@@ -322,13 +453,23 @@ def main():
                 layers.append((z[f'{a.net_prefix}W{i}'], z[f'{a.net_prefix}b{i}']))
                 i += 1
             net = dict(layers=layers)
-    r = run_closed_loop(sc=a.sc, num_samples=a.num_samples, N=a.N, C=a.C, verbose=a.verbose, eval_mode=a.eval_mode,
-                        value_net=net, device_resident=a.device_resident, cand_mode=a.cand_mode, dtype=a.dtype, graph=a.graph)
+    kw, policy_file = load_reference_configs(a.policy_config, a.env_config)
+    if a.N is not None:
+        kw['N'] = a.N
+    kw.setdefault('N', 40)
+    a.N = kw['N']
+    r = run_closed_loop(sc=a.sc, num_samples=a.num_samples, C=a.C, verbose=a.verbose, eval_mode=a.eval_mode,
+                        value_net=net, device_resident=a.device_resident, cand_mode=a.cand_mode, dtype=a.dtype, graph=a.graph, **kw)
+    if a.save_dir is not None:
+        policy = {'type': 'MPC', 'N': a.N, 'dt': kw.get('dt', 0.1), 'a_min': -4, 'a_max': 3, 'v_min': -1.0, 'v_max': 5,      # mpc.yaml's keys
+                  'prediction_type': 'constant_acceleration', 'collision_avoidance_type': 'circle', **policy_file, 'N': a.N,
+                  'solver': {'library': 'igtmpc', 'cand_mode': a.cand_mode, 'C': a.C, 'dtype': a.dtype, 'track_env': r.get('track_env')}}
+        r['run_dir'] = save_results(r, a.save_dir, a.eval_mode, a.sc, policy=policy)
     print(json.dumps({'sc': a.sc, 'episodes': a.num_samples, 'routes': r['routes'][:4],
                       'infeasible_ratio_mean': r['infeasible_ratio'].mean(axis=0).tolist(),
                       'deadlock_rate': float(r['deadlock'].mean()),
                       'final_s_mean': r['x_data'][:, 2::7, -1].mean(axis=0).tolist(),
-                      'avg_solve_ms_per_step': float(r['solve_ms'][5:].mean())}))
+                      'avg_solve_ms_per_step': float(r['solve_ms'][5:].mean()), 'run_dir': r.get('run_dir')}))
 
 
 if __name__ == '__main__':

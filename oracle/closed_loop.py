@@ -93,10 +93,12 @@ def augment_prev_sol(x_sol_prev, u_sol_prev, kp, P):
 
 
 def run_episode(x_init, routes, P, cinf, M_sim=30, cand_mode='lattice', C=256, refine_iters=0, warm_start=True,
-                u_init=None, eval_mode='mpc', net=None, track_env=1.0):
+                u_init=None, eval_mode='mpc', net=None, track_env=1.0, a_min_policy=A_MIN_POLICY, constant_speed=False):
     """x_init[M,7] (planner state order), routes = (route of agent 0, route of agent 1).
     eval_mode 'gt_mpc' needs net = dict(layers, Wn, mu_f, sigma_t, mu_t) (np_oracle.terminal_value).
     track_env: scale of the tracking family's acceleration envelope (the driver under test picks it from the horizon).
+    a_min_policy: mpc.yaml:8 a_min of the brake fallback (evaluate.py:514); constant_speed: the other agent is forecast with
+    a = 0 (mpc.yaml:13-14 prediction_type, evaluate.py:78-79, constant_acceleration_model.py:26-29).
     -> dict(x_data[7M, M_sim+1], u_data[2M, M_sim], infeasible[M], deadlock, events)."""
     M, N, dt = len(routes), P.N, P.dt
     assert M == 2
@@ -128,6 +130,8 @@ def run_episode(x_init, routes, P, cinf, M_sim=30, cand_mode='lattice', C=256, r
             a_fc = prev_in[j][0]
             if gt and t == 0:
                 a_fc = 0.0 + 0.09 * (j + 1)                                                # evaluate.py:207-210
+            if constant_speed:
+                a_fc = 0.0
             obs, tv = O.forecast_for_ego(routes[j], consts[routes[j]], cur[i][:2], cur[i][6], cur[j], a_fc, N, dt,
                                          None if plan is None else plan[0], None if plan is None else plan[1])
             flags = np.array([O.FLAG_ABS_HEADING if routes[i] in ABS_HEADING_ROUTES else 0], dtype=np.uint32)
@@ -156,7 +160,7 @@ def run_episode(x_init, routes, P, cinf, M_sim=30, cand_mode='lattice', C=256, r
             else:                                                                          # evaluate.py:511-545
                 infeasible[i] += 1
                 events['fallback'] += 1
-                a_fb = A_MIN_POLICY if cur[i][5] > 0 else 0.0
+                a_fb = a_min_policy if cur[i][5] > 0 else 0.0
                 df_fb = prev_in[i][1]
                 ns = O.frenet_rk4_step(cur[i], a_fb, df_fb, kp[i], P)
                 if cur[i][5] < 0:                                                          # evaluate.py:523-526

@@ -702,3 +702,69 @@ def test_plain_c_caller_gets_what_python_gets(tmp_path):
     assert int(np.nonzero(out['status'] == 0)[0][0]) == first and int(out['argmin'][first]) == cand
     assert abs(out['cost'][first] - cost) < 1e-5 and abs(out['u'][first, 0, 0] - a0) < 1e-4 and abs(out['u'][first, 1, 0] - df0) < 1e-4
     assert abs(out['x'][first, 2, N] - sN) < 1e-4
+
+
+@pytest.mark.parametrize('mode', ['mpc', 'gt_mpc'])
+def test_driver_command_line_writes_the_reference_run_directory(tmp_path, mode):
+    """`python -m igtmpc.evaluate --save_dir D/ --eval_mode M --sc 1 --num_samples 3` -- the reference's command line
+    (evaluate.py:643-650) -- leaves the reference driver's files: [episodes, 7 M, T+1] / [episodes, 2 M, T] arrays of a 15 s
+    run, one csv row per episode."""
+    import csv
+    import json
+    import pickle
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, 'igt-mpc-int_amd'))
+    out = subprocess.run([sys.executable, '-m', 'igtmpc.evaluate', '--save_dir', str(tmp_path) + '/', '--eval_mode', mode, '--sc', '1',
+                          '--num_samples', '3', '--N', '20'], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    run = line['run_dir']
+    assert os.path.basename(run).startswith(f'{mode}_sc1_seed2026_')
+    sub = run + ('/game_mpc/evaluation' if mode == 'gt_mpc' else '/mpc')
+    with open(sub + '/cl_traj.pkl', 'rb') as f:      # written by this test's own child process a moment ago
+        cl = pickle.load(f)
+    with open(sub + '/u_cl.pkl', 'rb') as f:
+        ucl = pickle.load(f)
+    assert cl.shape == (3, 14, 151) and ucl.shape == (3, 4, 150) and np.isfinite(cl).all() and np.isfinite(ucl).all()
+    assert (cl[:, 2::7, -1] >= cl[:, 2::7, 0]).all() and (cl[:, 5::7, 0] == 0).all()    # a standing start (v0 = 0), nobody rolled back
+    assert mode == 'gt_mpc' or (cl[:, 2::7, -1] > cl[:, 2::7, 0] + 20).all()          # (the shipped value nets run without their statistics)
+    with open(sub + ('/stats.csv' if mode == 'gt_mpc' else '/eval_stats.csv'), newline='') as f:
+        rows = list(csv.DictReader(f))
+    assert len(rows) == 3 and ('NN_query_time' in rows[0]) == (mode == 'gt_mpc')
+
+
+def test_closed_loop_with_the_policy_files_other_settings_matches_oracle_loop():
+    """What load_reference_configs hands on from mpc.yaml / fourwayint.yaml other than the shipped values: constant-speed
+    forecasts (mpc.yaml:14), a gentler brake fallback (a_min), a rolling start (v0) -- host loop and device-resident loop
+    against the oracle's loop with the same settings, 1e-9."""
+    import closed_loop as CL
+    from igtmpc import routes as R
+    from igtmpc.cinf import cinf_halfplanes
+    from igtmpc.evaluate import initial_states, run_closed_loop
+    pairs = [R.SCENARIO_ROUTES[0][0], R.SCENARIO_ROUTES[5][2], ('13', '23')]
+    x, _ = initial_states(np.random.default_rng(7), pairs, v0=2.0)
+    assert (x[:, :, 5] == 2.0).all()
+    # third episode: agent 0 outside the lane bound (brake fallback from step 0, so its forecast is never replaced by a shared
+    # plan) and fast enough that "holds 4 m/s" and "brakes at 2.5 m/s^2" put it on different sides of agent 1's path
+    for m, (r, s0, v0) in enumerate(zip(pairs[2], (17.0, 12.0), (4.0, 3.0))):
+        xy = R.frenet2global(R.ROUTE_ID[r], s0)
+        x[2, m] = (xy[0], xy[1], s0, 0.0, 0.0, v0, float(R.psi_ref(R.ROUTE_ID[r], s0)))
+    x[2, 0, 3] = 0.25
+    P = O.Params(N=20)
+    kw = dict(N=20, T_sim=2.5, dtype='f64', cand_mode='track', init=(x, pairs), a_min_policy=-2.5, constant_speed=True)
+    got = run_closed_loop(**kw)
+    dev = run_closed_loop(device_resident=True, **kw)
+    plain = run_closed_loop(**dict(kw, constant_speed=False))
+    assert not np.array_equal(got['x_data'], plain['x_data'])          # the switch reaches the forecast
+    fb = 0
+    for e in range(len(pairs)):
+        ref = CL.run_episode(x[e], pairs[e], P, cinf_halfplanes(), M_sim=25, cand_mode='track', track_env=got['track_env'],
+                             a_min_policy=-2.5, constant_speed=True)
+        fb += ref['events']['fallback']
+        for r in (got, dev):
+            assert rel_err(r['x_data'][e], ref['x_data']).max() < 1e-9, (e, pairs[e])
+            assert rel_err(r['u_data'][e], ref['u_data']).max() < 1e-9, (e, pairs[e])
+    assert fb > 0
+    assert (got['u_data'][2, 0, :3] == -2.5).all()                    # the fallback brakes with the policy file's a_min

@@ -477,3 +477,77 @@ def test_shipped_library_is_built_without_the_developer_kernels(monkeypatch):
         assert L.wants_dev_kernels() and L.load() is dev
     monkeypatch.setenv('IGT_DEV_FLAGS', '4')                       # switches of the production kernels stay available
     assert not L.wants_dev_kernels() and L.load() is shipped
+
+
+def test_save_results_leaves_the_reference_drivers_run_directory(tmp_path):
+    """igtmpc.evaluate.save_results (evaluate.py:319-369, 578-640): directory names, file names, array layouts and csv columns
+    of the reference's driver -- cl_traj.pkl is [episodes, 7 M, T+1] so that generate_video.py:191 `cl_traj[index]` gets one
+    episode's [7 M, T+1]; a second call on the same run directory appends episodes as the reference's iterations do."""
+    import csv
+    import pickle
+    from igtmpc.evaluate import save_results
+    rng = np.random.default_rng(0)
+    E, M, T = 3, 2, 5
+    r = dict(x_data=rng.normal(size=(E, 7 * M, T + 1)), u_data=rng.normal(size=(E, 2 * M, T)),
+             infeasible_ratio=rng.uniform(size=(E, M)), deadlock=np.array([True, False, False]),
+             routes=[('13', '24'), ('24', '31'), ('31', '42')], solve_ms=np.array([0.5, 0.25, 0.25, 0.25, 0.25]))
+    base = str(tmp_path) + '/'
+    for mode, sub, stats, cols in (('mpc', '/mpc', 'eval_stats.csv', ['avg_sol_times', 'std_solve_times', 'infeasible_ratio', 'deadlock']),
+                                   ('gt_mpc', '/game_mpc/evaluation', 'stats.csv',
+                                    ['NN_query_time', 'avg_sol_times', 'std_solve_times', 'infeasible_ratio', 'deadlock'])):
+        run = save_results(r, base, mode, 3, policy={'type': 'MPC', 'N': 40}, timenow='20261004_000000')
+        assert run == base + mode + '_sc3_seed2026_20261004_000000'          # evaluate.py:325: plain concatenation
+        assert os.path.isdir(run + sub.replace('/evaluation', '') + '/evaluation_videos')
+        save_results(r, base, mode, 3, policy={'type': 'MPC', 'N': 40}, timenow='20261004_000000')
+        with open(run + sub + '/cl_traj.pkl', 'rb') as f:
+            cl = pickle.load(f)
+        with open(run + sub + '/u_cl.pkl', 'rb') as f:
+            ucl = pickle.load(f)
+        assert cl.shape == (2 * E, 7 * M, T + 1) and ucl.shape == (2 * E, 2 * M, T)
+        assert np.array_equal(cl[:E], r['x_data']) and np.array_equal(cl[E:], r['x_data']) and np.array_equal(ucl[E:], r['u_data'])
+        with open(run + sub + '/' + stats, newline='') as f:
+            rows = list(csv.DictReader(f))
+        assert list(rows[0].keys()) == cols and len(rows) == 2 * E
+        assert [row['deadlock'] for row in rows[:E]] == ['True', 'False', 'False']
+        assert rows[1]['infeasible_ratio'] == str(np.asarray(r['infeasible_ratio'][1]))      # numpy's text, as the reference's rows
+        assert abs(float(rows[0]['avg_sol_times'].strip('[]').split()[0]) - 0.3e-3) < 1e-12   # seconds
+        import yaml
+        assert yaml.safe_load(open(run + sub + '/mpc.yaml'))['N'] == 40
+        if mode == 'mpc':
+            with open(run + sub + '/evaluation_data.pkl', 'rb') as f:
+                d = pickle.load(f)
+            assert d['x_cl'].shape == cl.shape and d['routes'].shape == (2 * E, M) and d['deadlock'].shape == (2 * E, 1)
+            assert d['N'] == 40 and d['agent_types'] == ['CAV', 'CAV'] and d['initial_agents'].shape == (2 * E, M, 7)
+
+
+def test_load_reference_configs_reads_the_reference_files_and_refuses_another_intersection(tmp_path):
+    """igtmpc.evaluate.load_reference_configs: mpc.yaml / fourwayint.yaml with the reference's keys (values as shipped,
+    mpc.yaml:1-15, fourwayint.yaml:1-32, restated here as data) -> run_closed_loop keywords; prediction_type is matched the way
+    evaluate.py:76-81 matches it; a road the frozen route tables were not generated for, a third agent, obca or an unknown
+    prediction type are refused."""
+    import yaml
+    from igtmpc.evaluate import load_reference_configs
+    pol = {'type': 'MPC', 'NN_type': 't+N', 'input_sequence_length': 5, 'N': 40, 'dt': 0.1, 'a_min': -4, 'a_max': 3,
+           'v_min': -1.0, 'v_max': 5, 'prediction_type': 'constant_acceleration', 'collision_avoidance_type': 'circle'}
+    env = {'render_fps': 10, 'dt': 0.1, 'road_width': 11.4, 'width_buffer': 0.2, 'road_length': 50, 'fillet_radius': 8.4,
+           'ca_radius': 2.8, 'num_agents': 2, 'v0': 0, 'v_des': 5, 'width': 2.0, 'length': 4.47, 'l_r': 2.235, 'l_f': 2.235,
+           'a_max': 3.0, 'a_min': -4.0, 'v_max': 20.0, 'v_min': -2.0, 'steering_min': -0.6, 'steering_max': 0.6}
+
+    def files(p, e):
+        pp, ee = tmp_path / 'mpc.yaml', tmp_path / 'fourwayint.yaml'
+        pp.write_text(yaml.safe_dump(p))
+        ee.write_text(yaml.safe_dump(e))
+        return str(pp), str(ee)
+
+    kw, policy = load_reference_configs(*files(pol, env))
+    assert kw == {'constant_speed': False, 'N': 40, 'a_min_policy': -4.0, 'dt': 0.1, 'v0': 0.0,
+                  'limits': {'l_r': 2.235, 'l_f': 2.235}}
+    assert policy == pol
+    assert load_reference_configs(*files(dict(pol, prediction_type='constant_speed', N=10, a_min=-2.5), env))[0] == {
+        'constant_speed': True, 'N': 10, 'a_min_policy': -2.5, 'dt': 0.1, 'v0': 0.0, 'limits': {'l_r': 2.235, 'l_f': 2.235}}
+    assert load_reference_configs(None, None) == ({}, {})
+    for bad_p, bad_e in ((dict(pol, collision_avoidance_type='obca'), env), (dict(pol, prediction_type='kalman'), env),
+                         (dict(pol, type='RL'), env), (pol, dict(env, road_width=12.0)), (pol, dict(env, num_agents=3)),
+                         (pol, dict(env, ca_radius=3.0)), (pol, dict(env, v_max=10.0)), (dict(pol, dt=0.05), env)):
+        with pytest.raises(ValueError):
+            load_reference_configs(*files(bad_p, bad_e))
