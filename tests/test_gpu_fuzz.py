@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import np_oracle as O
-from helpers import ambiguous_mask, oracle_params, rel_err
+from helpers import F32_EPS, F32_TIE, REL_TOL, ambiguous_mask, oracle_params, rel_err
 
 
 def _draw(seed):
@@ -48,22 +48,39 @@ def _draw(seed):
     return cfg
 
 
-N_SEEDS = 48
+N_SEEDS = 40
+F32_SEEDS = range(100, 118)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('seed', range(N_SEEDS))
 def test_random_configuration_matches_oracle(seed, golden_dir):
+    _run(seed, golden_dir, 'f64')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', F32_SEEDS)
+def test_random_configuration_matches_oracle_f32(seed, golden_dir):
+    """The float32 entry points on the same kind of draws, at BASELINE.json's 1e-5 with the float32 set-asides of
+    test_gpu_parity.py (threshold / break-point within 1e-7, near-ties; value network: 2e-5)."""
+    _run(seed, golden_dir, 'f32')
+
+
+def _run(seed, golden_dir, dtype):
     import igtmpc
     from igtmpc.cinf import cinf_halfplanes
     from igtmpc.scenarios import make_batch
     cfg = _draw(seed)
     N, dt, C, B = cfg['N'], cfg['dt'], cfg['C'], cfg['B']
-    b = make_batch(max(B, 8), N=N, dt=dt, seed=100 + seed, dtype=np.float64)
+    f32 = dtype == 'f32'
+    npdt = np.float32 if f32 else np.float64
+    tol, utol = (REL_TOL, 1e-7 if cfg['cand'] != 'track' else REL_TOL) if f32 else (1e-9, 1e-12)
+    eps, tie = ((2e-5, 2e-5) if cfg['net'] else (F32_EPS, F32_TIE)) if f32 else (1e-9, 1e-9)
+    b = make_batch(max(B, 8), N=N, dt=dt, seed=100 + seed, dtype=npdt)
     b = {k: np.ascontiguousarray(v[:B]) for k, v in b.items() if isinstance(v, np.ndarray) and len(v) >= B}
     obs = b['obs_xy']                                                  # [B, 1, 2, N+1]
     if cfg['n_obs'] == 0:
-        obs = np.zeros((B, 0, 2, N + 1))
+        obs = np.zeros((B, 0, 2, N + 1), dtype=npdt)
     elif cfg['n_obs'] == 2:                                            # a second vehicle, 9 m behind the first along its path
         lag = obs.copy()
         lag[:, 0, 0, :] -= 9.0 * np.cos(0.3 * np.arange(B))[:, None]
@@ -74,8 +91,8 @@ def test_random_configuration_matches_oracle(seed, golden_dir):
     if cfg['warm']:       # previous solution = some lattice candidate of the scenario, shifted by one step (utils.py:354-363)
         P0 = O.Params(N=N, dt=dt)
         prev = O.candidates_lattice(b['u_prev'], P0)[np.arange(B), (np.arange(B) * 37 + seed) % 256]
-        u_ws = np.ascontiguousarray(O.shift_controls(prev))
-        u_prev = np.ascontiguousarray(prev[:, :, 0])
+        u_ws = np.ascontiguousarray(O.shift_controls(prev).astype(npdt))
+        u_prev = np.ascontiguousarray(prev[:, :, 0].astype(npdt))
         flags = flags | np.where(np.arange(B) % 3 != 0, 2, 0).astype(np.uint32)
     net, extra = None, ()
     if cfg['net']:
@@ -88,7 +105,7 @@ def test_random_configuration_matches_oracle(seed, golden_dir):
                    mu_f=np.array([20.0, 2.5, 0.0, 0.0, 0.0, 0.0]) + 0.1 * rng.normal(size=6), sigma_t=float(rng.choice([1.0, 3.0, -2.0])),
                    mu_t=float(rng.normal()))
         extra = (b['tv_sv'], b['enc'])
-    with igtmpc.BatchSolver(N=N, dt=dt, n_rk4=cfg['n_rk4'], C=C, n_obs=cfg['n_obs'], dtype='f64', cand_mode=cfg['cand'],
+    with igtmpc.BatchSolver(N=N, dt=dt, n_rk4=cfg['n_rk4'], C=C, n_obs=cfg['n_obs'], dtype=dtype, cand_mode=cfg['cand'],
                             refine_iters=cfg['refine'], cost_mode='value_net' if net else 'progress', **cfg['limits']) as s:
         P = oracle_params(s)
         cinf = cinf_halfplanes(dt=dt, jerk=s.params.jerk_limit) if cfg['terminal'] else (None, None)
@@ -102,7 +119,9 @@ def test_random_configuration_matches_oracle(seed, golden_dir):
         allc = s.rollout_all(b['x0'][:n_all], u_prev[:n_all], b['kparams'][:n_all], flags[:n_all], obs[:n_all],
                              *[e[:n_all] for e in extra], u_ws=None if u_ws is None else u_ws[:n_all])
     f = lambda k: np.asarray(b[k], dtype=np.float64)
-    o = obs if cfg['n_obs'] else None
+    o = obs.astype(np.float64) if cfg['n_obs'] else None
+    u_prev = u_prev.astype(np.float64)
+    u_ws = None if u_ws is None else u_ws.astype(np.float64)
     kw = dict(net=net, tv_sv=f('tv_sv'), enc=f('enc')) if net else {}
     if cfg['cand'] == 'lattice':
         passes = [O.solve_batch(f('x0'), u_prev, f('kparams'), flags, o, cinf[0], cinf[1], P, C=C, return_all=True, **kw)]
@@ -115,29 +134,34 @@ def test_random_configuration_matches_oracle(seed, golden_dir):
     # every candidate of the first pass: controls, trajectories, verdicts (the refinement passes re-centre on a winner)
     if cfg['refine'] == 0:
         bp_all = O.breakpoint_distance(x0[:n_all], first['U'][:n_all], kp[:n_all], P)
-        clear = bp_all > 1e-9
-        assert rel_err(allc['U'][clear], first['U'][:n_all][clear]).max() <= 1e-12, cfg
+        clear = bp_all > eps
+        if f32:     # float32 error grows with the excursion: only roll-outs that stay near the lane are held to 1e-5 (every
+                    # feasible one does: |e_y| <= ey_lim)
+            clear &= (np.abs(first['X'][:n_all, :, 3, :]).max(axis=-1) <= 1.0) & (np.abs(first['X'][:n_all, :, 4, :]).max(axis=-1) <= 0.5)
+        if not clear.any():
+            clear[...] = False
+        assert clear.sum() == 0 or rel_err(allc['U'][clear], first['U'][:n_all][clear]).max() <= utol, cfg
         # ... those that stay clear of the model's singularity 1 - K e_y = 0 (frenet.py:73): a wild candidate of a long horizon
         # drifts tens of metres off the lane, and next to the pole rounding differences are amplified without bound
         # (seed 31: min |1 - K e_y| = 2.7e-4, 0.25 relative).  Every FEASIBLE candidate has |e_y| <= ey_lim and is compared.
         pole = np.abs(1.0 - kp[:n_all, :, 2:3] * first['X'][:n_all, :, 3, :]).min(axis=-1) > 0.1
         fin = clear & pole & np.isfinite(first['X'][:n_all]).all(axis=(-1, -2))
         assert (first['feas'][:n_all] <= pole).all()
-        assert rel_err(allc['X'][fin], first['X'][:n_all][fin]).max() <= 1e-9, cfg
-        thr = fin & (np.abs(first['g'][:n_all] - P.feas_tol) > 1e-9)
+        assert fin.sum() == 0 or rel_err(allc['X'][fin], first['X'][:n_all][fin]).max() <= tol, cfg
+        thr = fin & (np.abs(first['g'][:n_all] - P.feas_tol) > (1e-6 if f32 else 1e-9))
         assert ((allc['viol'] == 0) == first['feas'][:n_all])[thr].all(), cfg
     # the solve: a scenario is set aside when ANY pass decided it inside 1e-9 (a different winner re-centres the next pass)
     amb = np.zeros(B, dtype=bool)
     for r in passes:
-        amb |= ambiguous_mask(r, P, 1e-9, 1e-9, 1e-9, O.breakpoint_distance(x0, r['U'], kp, P))
+        amb |= ambiguous_mask(r, P, eps, tie, eps, O.breakpoint_distance(x0, r['U'], kp, P))
     ok = ~amb
     assert (got['status'][ok] == ref['status'][ok]).all(), cfg
     assert (got['argmin'][ok] == ref['argmin'][ok]).all(), cfg
     sol = ok & (ref['status'] == 0)
     if sol.any():
-        assert rel_err(got['x'][sol], ref['x'][sol]).max() <= 1e-9, cfg
-        assert rel_err(got['u'][sol], ref['u'][sol]).max() <= 1e-9, cfg
-        assert rel_err(got['cost'][sol], ref['cost'][sol]).max() <= 1e-9, cfg
+        assert rel_err(got['x'][sol], ref['x'][sol]).max() <= tol, cfg
+        assert rel_err(got['u'][sol], ref['u'][sol]).max() <= max(tol, utol), cfg
+        assert rel_err(got['cost'][sol], ref['cost'][sol]).max() <= (2e-5 if f32 and cfg['net'] else tol), cfg
     bad = got['status'] == 1
     assert np.isnan(got['x'][bad]).all() and np.isinf(got['cost'][bad]).all() and (got['argmin'][bad] == -1).all(), cfg
 
@@ -150,6 +174,9 @@ def test_the_draws_cover_the_template_space():
     assert {c['net'] for c in cfgs} == {0, 1, 3} and any(c['warm'] for c in cfgs)
     assert any(c['net'] and c['cand'] == 'track' for c in cfgs) and any(c['net'] and c['refine'] for c in cfgs)
     assert any(c['B'] * c['C'] // 64 > 1024 for c in cfgs) and any(c['B'] * c['C'] // 64 <= 1024 and c['B'] > 8 for c in cfgs)
+    f32 = [_draw(s) for s in F32_SEEDS]
+    assert {c['cand'] for c in f32} == {'lattice', 'ramp_hold', 'track'} and any(c['net'] for c in f32) and any(c['warm'] for c in f32)
+    assert {c['C'] for c in f32} == {64, 256, 1024} and any(c['n_rk4'] != 4 for c in f32) and any(c['refine'] for c in f32)
     assert {c['n_rk4'] == 4 for c in cfgs} == {True, False}
     assert {c['C'] for c in cfgs} == {64, 256, 1024}
     assert {c['cand'] for c in cfgs} == {'lattice', 'ramp_hold', 'track'}
