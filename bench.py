@@ -447,34 +447,27 @@ def main():
         # independent), so the exchange of step t runs on its own stream under the search pass of step t+1,
         # double-buffered; the timed region ends with a device-wide synchronize, i.e. with every exchange complete.
         if exchange:
-            comm = torch.cuda.Stream(dev)
-            u0_buf = [torch.empty((Bm, 2), dtype=td, device=f'cuda:{dev}') for _ in range(2)]
-            gathered = [torch.empty((Bm * world, 2), dtype=td, device=f'cuda:{dev}') for _ in range(2)]
-            ev_ready = [torch.cuda.Event() for _ in range(2)]
-            ev_free = [torch.cuda.Event() for _ in range(2)]
-            for e in ev_free:
-                e.record(comm)
+            # one staging buffer and one gathered vector per lane: a lane's exchange is ordered behind its own solve and
+            # ahead of its next one by the lane's stream alone
+            u0_buf = [torch.empty((Bm, 2), dtype=td, device=f'cuda:{dev}') for _ in range(F)]
+            gathered = [torch.empty((Bm * world, 2), dtype=td, device=f'cuda:{dev}') for _ in range(F)]
         step_no = [0]
 
         def step():
-            # step t on handle / stream t mod F; the inputs are read-only, every lane has its own outputs.  The staging
-            # copy of u*[:, :, 0] runs on the lane's own stream right behind the solve (so the lane's next solve cannot
-            # overwrite what is still being copied); the all-gather runs on the communication stream.
+            # step t on handle / stream t mod F; the inputs are read-only, every lane has its own outputs and its own exchange
+            # buffers.  The staging copy of u*[:, :, 0] and the all-gather are enqueued behind the lane's solve (the collective
+            # itself runs on the process group's stream, which waits for the lane and which the lane waits for).  The search
+            # kernels are persistent -- every wave slot stays taken until a search pass drains -- so each small kernel of
+            # another stream gets on the chip at the next drain: a lane's copy and collective add latency to that lane, not
+            # device time, and the other lanes' solves cover it.
             q = step_no[0] % F
-            lane = lanes[q] if F > 1 else torch.cuda.current_stream(dev)
-            i = step_no[0] & 1
+            lane = lanes[q] if lanes[q] is not None else torch.cuda.current_stream(dev)
             step_no[0] += 1
             with torch.cuda.stream(lane):
                 solvers[q].solve(*dargs, out=outs[q])
                 if exchange:
-                    lane.wait_event(ev_free[i])                # the exchange two steps back has released buffer i
-                    u0_buf[i].copy_(outs[q]['u'][:, :, 0])
-                    ev_ready[i].record(lane)
-            if exchange:
-                with torch.cuda.stream(comm):
-                    comm.wait_event(ev_ready[i])
-                    dist.all_gather_into_tensor(gathered[i], u0_buf[i])
-                    ev_free[i].record(comm)
+                    u0_buf[q].copy_(outs[q]['u'][:, :, 0])
+                    dist.all_gather_into_tensor(gathered[q], u0_buf[q])
 
         def fence():
             torch.cuda.synchronize(dev)
@@ -487,6 +480,8 @@ def main():
         settle = args.settle_ms if settle_ms is None else settle_ms
         n_settle = 0
         if settle > 0:
+            if exchange:                       # the first collective sets the communicator up: not a step time
+                step(); torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             step(); torch.cuda.synchronize(dev)
             per = max(time.perf_counter() - t0, 1e-5)
@@ -503,6 +498,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        issued = time.perf_counter() - t0          # host time to enqueue the timed steps (close to `elapsed`: host-bound)
         fence()
         elapsed = time.perf_counter() - t0
         if exchange:
@@ -541,7 +537,7 @@ def main():
         rd, wr = solver.algorithmic_bytes_per_solve()
         res = dict(dtype=dtype, B=Bm, elapsed=elapsed, steps=steps, value=Bm * n_gpus * steps / elapsed,
                    ms_per_step=elapsed / steps * 1e3, search_ms=float(np.mean(ks)), emit_ms=float(np.mean(ke)),
-                   lane_search_ms=lane_s, lane_emit_ms=lane_e, in_flight=F, settle_steps=n_settle,
+                   lane_search_ms=lane_s, lane_emit_ms=lane_e, in_flight=F, settle_steps=n_settle, host_issue_ms=issued / steps * 1e3,
                    rd=rd, wr=wr, feasible=float((out['status'] == 0).float().mean().item()), batch=batch)
         for sv in solvers:
             sv.close()
@@ -589,6 +585,7 @@ def main():
         line = assemble_line(args, head, n_gpus, world, backend, exchange, other=other, serial=serial, tracking=tracking,
                              same_work=same_work, configs=configs, cpu=cpu, n_layers=n_layers)
         line['config']['settle_steps'] = head['settle_steps']
+        line['host_issue_ms_per_step'] = head.get('host_issue_ms')      # host time to enqueue one step; near ms_per_step: host-bound
         print(json.dumps(line), flush=True)
     if exchange:
         dist.barrier()
