@@ -137,7 +137,7 @@ igt::KP make_kp(const igt_params& p, int F) {
     k.G = p.cand_mode == IGT_CAND_TABLE ? 1 : isqrt_exact(p.C);
     k.refine_it = 0;
     k.df_small = p.df_max < 0.78 ? 1 : 0;
-    { const char* e = getenv("IGT_DEV_FLAGS"); k.dev = e ? atoi(e) : 0; }
+    { const char* e = getenv("IGT_DEV_FLAGS"); k.dev = (e ? atoi(e) : 0) & 0x3FFFFFFF; }      // bit 30 is set by the launchers
     k.dt = p.dt;
     k.h = p.dt / p.n_rk4;                      // frenet.py:93
     k.l_r = p.l_r;
@@ -331,11 +331,11 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     double* d_cpar = nullptr;
     {
         const size_t n_rec = value ? (size_t)B * p.C : 0;
-        const size_t need = traj_doubles * 8 + 256 + (size_t)B * W * 12 + (size_t)B * 56 + 8192 + ckpt_bytes + (size_t)(B + 8) * Wk * 36 + 256 + n_rec * (2 * sizeof(T) + 16) +
+        const size_t need = traj_doubles * 8 + 256 + (size_t)B * 8 + 256 + (size_t)B * W * 12 + (size_t)B * 56 + 8192 + ckpt_bytes + (size_t)(B + 8) * Wk * 36 + 256 + n_rec * (2 * sizeof(T) + 16) +
                             (value ? (size_t)B * igt::VN_H * sizeof(T) + (size_t)B * Wk * 8 + (size_t)B * 8 + n_rec * 4 + 512 : 0) + 20 * 256;
         if (int rc = ensure_work(h, need, st)) return rc;
         Arena wa{(char*)h->d_work, 0};
-        A.part_J = wa.take<double>((size_t)B * W);
+        A.part_J = wa.take<double>((size_t)B * W + (sizeof(T) == 8 ? (size_t)B : 0));      // double path: + [B] live-row masks (igt_kernels_f64.hip)
         A.part_c = wa.take<int32_t>((size_t)B * W);
         d_cpar = wa.take<double>((size_t)B * 4);
         const bool trace = (h->kp.dev & 256) != 0;      // developer trace: 32 B per unit behind the counters
@@ -348,6 +348,7 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
         // nothing from 8192 on)
         A.queue_order = B <= 6144 ? wa.take<unsigned>((size_t)((B + 7) / 8) * 8 * Wk) : nullptr;
         if constexpr (sizeof(T) == 8) A.traj = capture ? wa.take<double>(traj_doubles) : nullptr;
+        if constexpr (sizeof(T) == 8) A.row_mask = reinterpret_cast<unsigned long long*>(A.part_J + (size_t)B * W);
         if (value) {
             A.rec_J = wa.take<double>(n_rec);
             A.rec_sN = wa.take<T>(n_rec);

@@ -316,6 +316,8 @@ __device__ __forceinline__ void terminal_viol2(const KP& P, const double (&v)[2]
 // ---------------------------------------------------------------------------------------
 // one rollout pass over NC candidates of one scenario
 // ---------------------------------------------------------------------------------------
+constexpr int STEER_TABLE_MAX_ENTRIES = 320;     // steering columns x N of one float64 search unit's LDS table (igt_fast64.h)
+
 template <typename T>
 struct Scenario {           // wave-uniform inputs of one scenario
     double x0[7];

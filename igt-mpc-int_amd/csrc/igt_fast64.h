@@ -312,17 +312,17 @@ __device__ __forceinline__ void slip_trig(const KP& P, double lr_ratio, double d
 // step that depend on nothing but the column.  The unit's wave lays the columns out once in LDS, [k][column][df, sin,
 // cos] (the angles sequentially on one lane per column -- the recursion is the candidates' own -- then the trigonometry
 // of all entries in parallel), with the same functions the untabulated roll-out calls: the same bits.
-constexpr int STAB_MAX_ENTRIES = 320;        // columns x N per unit (C = 256: 4 x 20, N = 40: 160; C = 64: 8 x 40)
+constexpr int STAB_MAX_ENTRIES = STEER_TABLE_MAX_ENTRIES;        // columns x N per unit (C = 256: 4 x 20, N = 40: 160; C = 64: 8 x 40)
 template <int CAND>
 __device__ __forceinline__ void fill_steer_table(const KP& P, const Scenario<double>& S, int nj, int p, int lane,
                                                  double lr_ratio, double* __restrict__ stab) {
     if (lane < nj) {
-        const int r = p * nj + lane;
-        const int j = (r & 1) ? P.G / 2 - 1 - (r >> 1) : P.G / 2 + (r >> 1);      // slice_candidate64's column order
-        const double ddf = steer_column<CAND>(P, S, j);
+        const int r = p * nj + lane;                                              // the last unit may hold fewer than nj columns
+        const int j = (r & 1) ? P.G / 2 - 1 - (r >> 1) : P.G / 2 + (r >> 1);      // unit_candidate's column order
+        const double ddf = r < P.G ? steer_column<CAND>(P, S, j) : 0.0;
         double df = S.df_prev;
         for (int k = 0; k < P.N; ++k) {
-            df = steer_next<CAND>(P, S, k, ddf, df);
+            df = r < P.G ? steer_next<CAND>(P, S, k, ddf, df) : 0.0;
             stab[(k * nj + lane) * 3] = df;
         }
     }
@@ -353,7 +353,10 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
     fp.init(P, S.b0, S.b1, S.kv);
     double x = S.x0[0], y = S.x0[1], s = S.x0[2], ey = S.x0[3], ep = S.x0[4], v = S.x0[5], psi = S.x0[6];
     double a = S.a_prev, df = S.df_prev, da = 0.0, ddf = 0.0, J = 0.0, gmax = -1.0e300;
-    unsigned viol = 0;
+    // cidx < 0 (search): a lane of the unit that holds no candidate (igt_kernels_f64.hip unit_candidate) -- it rolls candidate 0
+    // in step with the wave and is "lost" from the start, so it neither wins nor keeps the unit alive
+    unsigned viol = cidx < 0 ? (unsigned)VIOL_EY : 0u;
+    if (cidx < 0) cidx = 0;
     bool dead = false;
     if (CAND == CAND_LATTICE) {
         // da_i = -ra + (2 ra) i/(G-1), ddf_j likewise (oracle candidates_lattice)

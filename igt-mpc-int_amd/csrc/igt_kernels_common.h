@@ -83,6 +83,75 @@ __device__ __forceinline__ int queue_scenario(int q, int j) { return 8 * j + ((q
 //   * the centre-steering slice runs (nearly) the whole horizon; the others leave through the early exit after a
 //     number of steps that falls with the speed (|e_y| grows with v: 18 steps at v0 < 1 m/s, 9 at v0 > 4);
 //   * a scenario that meets its arc within the horizon rolls the long sub-step variants (about 1.9x per step).
+// ---- units of the float64 search (igt_kernels_f64.hip: "Acceleration rows that cannot win") ----
+struct UnitLayout {
+    int kind;                       // 0: 64 candidates in index order, 1: acceleration-axis units, 2: steering slices
+    int per;                        // kind 1: rows per unit, kind 2: steering columns per unit
+    int n_units, R;
+    unsigned long long mask;        // live acceleration rows
+};
+// x / d for 0 <= x < 4096, 1 <= d <= 64 through the float reciprocal: (x + 1/2) / d is at least 1/128 away from an integer, the
+// float error is below 1e-3 of that -- exact, and a tenth of the instructions of an integer division by a run-time value
+__device__ __forceinline__ int small_div(int x, int d) {
+    return (int)(((float)x + 0.5f) * __builtin_amdgcn_rcpf((float)d));
+}
+// whether the steering table of a slice fits LDS with the layout's own G / W columns (then `per` is kept within it)
+__device__ __forceinline__ bool steer_table_fits(const KP& P, int W, int cand) {
+    return (cand == CAND_LATTICE || cand == CAND_RAMP_HOLD) && (P.G / W) * P.N <= STEER_TABLE_MAX_ENTRIES && !(P.dev & 4);
+}
+__device__ __forceinline__ UnitLayout unit_layout(const KP& P, int W, int cand, unsigned long long mask) {
+    UnitLayout L;
+    const bool slices = cand != CAND_TABLE && P.G * P.G == P.C && W * 64 == P.C && P.G % W == 0 && !(P.dev & 1);
+    if (!slices) { L.kind = 0; L.per = 64; L.n_units = W; L.R = P.G; L.mask = ~0ull; return L; }
+    L.mask = mask & (P.G >= 64 ? ~0ull : ((1ull << P.G) - 1ull));
+    L.R = __popcll(L.mask);
+    const int nj = 64 / P.G;                                 // = G / W (C = G^2 = 64 W; G is a power of two, igt_api.hip)
+    if (cand == CAND_TRACK && !(P.dev & 262144)) {
+        L.kind = 1; L.per = nj;
+        L.n_units = (L.R + nj - 1) / nj;                     // nj is a power of two as well
+        return L;
+    }
+    L.kind = 2;
+    int per = L.R > 0 ? small_div(64, L.R) : P.G;
+    if (per > P.G) per = P.G;
+    if (steer_table_fits(P, W, cand)) { const int cap = small_div(STEER_TABLE_MAX_ENTRIES, P.N); if (per > cap) per = cap; }
+    // the float detour leaves these in vector registers although they are the same on every lane: back to scalars, or the
+    // stride of the steering table is recomputed on the vector ALU at every control step
+    L.per = __builtin_amdgcn_readfirstlane(per);
+    L.n_units = __builtin_amdgcn_readfirstlane(L.R > 0 ? small_div(P.G + per - 1, per) : 0);
+    return L;
+}
+// rank -> row of the live acceleration rows, laid out in LDS by the unit's wave (one workgroup = one wave): lane i, if row i is
+// live, stores i at the number of live rows below it
+__device__ __forceinline__ void rows_by_rank(const UnitLayout& L, int lane, int* __restrict__ rank2row) {
+    if (L.kind != 0) {
+        if ((L.mask >> lane) & 1ull) rank2row[__popcll(L.mask & ((1ull << lane) - 1ull))] = lane;
+    }
+    __syncthreads();
+}
+// candidate of lane `lane` of unit p, or -1 for a lane that holds none (rank2row: rows_by_rank's table, or null: searched)
+__device__ __forceinline__ int unit_candidate(const KP& P, const UnitLayout& L, int p, int lane, const int* __restrict__ rank2row) {
+    if (L.kind == 0) return p * 64 + lane;
+    const int lg = __ffs(P.G) - 1;                           // G is a power of two
+    int rank, j;
+    if (L.kind == 1) {                                       // lane = il * G + j
+        rank = p * L.per + (lane >> lg);
+        j = lane & (P.G - 1);
+    } else {                                                 // lane = il * per + jl; column rank r, handed out from the centre outwards
+        const int il = small_div(lane, L.per), r = p * L.per + (lane - il * L.per);
+        rank = (r < P.G) ? il : L.R;
+        j = (r & 1) ? P.G / 2 - 1 - (r >> 1) : P.G / 2 + (r >> 1);
+    }
+    if (rank >= L.R) return -1;
+    int row;
+    if (rank2row) row = rank2row[rank];
+    else { unsigned long long m = L.mask; for (int t = 0; t < rank; ++t) m &= m - 1ull; row = __ffsll((long long)m) - 1; }
+    return (row << lg) + j;
+}
+__device__ __forceinline__ int units_of_live_rows(const KP& P, int W, unsigned long long mask) {
+    return unit_layout(P, W, P.cand_mode, mask).n_units;
+}
+
 // One workgroup per queue sorts its units into QC cost classes, most expensive first, keeping the scenario order
 // inside a class (a stable counting sort, so the order is a function of the inputs alone).
 // order[q][k] = (scenario ordinal in the queue) * 256 + slice.
@@ -91,7 +160,8 @@ template <typename T>
 __global__ __launch_bounds__(QB_THREADS) void build_queues_kernel(KP P, int B, int W, const T* __restrict__ x0,
                                                                   const T* __restrict__ kparams,
                                                                   unsigned* __restrict__ order, int stride,
-                                                                  unsigned* __restrict__ work_counter) {
+                                                                  unsigned* __restrict__ work_counter,
+                                                                  const unsigned long long* __restrict__ row_mask = nullptr) {
     __shared__ int cnt[QB_TRIPS][QB_THREADS / 64][QC];   // [trip][wave][class] counts, then exclusive offsets
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) work_counter[q * 64] = 0u;             // this queue's unit counter (saves the memset node)
@@ -104,7 +174,7 @@ __global__ __launch_bounds__(QB_THREADS) void build_queues_kernel(KP P, int B, i
         if (i < n) {
             const int j = i / W, p = i - j * W, b = queue_scenario(q, j);
             c = QC - 1;                                  // a hole of the last block of 8: sorts last, skipped by the search
-            if (b < B) {
+            if (b < B && (!row_mask || p < units_of_live_rows(P, W, row_mask[b]))) {      // a slice beyond the live rows' units: a hole too
                 const float s0 = (float)x0[(size_t)b * 7 + 2], v0 = (float)x0[(size_t)b * 7 + 5];
                 const float b0 = (float)kparams[(size_t)b * 3 + 0], b1 = (float)kparams[(size_t)b * 3 + 1], kv = (float)kparams[(size_t)b * 3 + 2];
                 const float reach = s0 + 1.5f * fmaxf(v0, 1.0f) * (float)(P.N * P.dt);

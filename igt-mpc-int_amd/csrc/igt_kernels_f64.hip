@@ -156,18 +156,65 @@ __device__ __forceinline__ bool steering_slices64(const KP& P, int W) {
 // what the ACCELERATION profile decides (collision, speed box, terminal set), so its units are cut along the acceleration
 // axis instead -- unit p takes G/W consecutive acceleration offsets with all G steering offsets (tools/death_steps_track.py:
 // 90.8 % of the wave-steps executed against 94.1 % with steering slices).
+//
+// Acceleration rows that cannot win.  In the generated families the acceleration sequence of candidate (i, j) depends on the
+// row i alone, the speed is v_{k+1} = v_k + dt a_k, and two of the verdicts -- the speed box (mpc.py:316-317) and the terminal
+// set on (v_{N-1}, a_{N-1}) (mpc.py:177-180) -- read nothing else: a row that fails one of them is infeasible in all of its
+// G columns whatever the steering does.  accel_rows_kernel rolls the G scalar recurrences of a scenario ahead of the search
+// (the same expressions as rollout_one, so the same bits) and leaves the rows that survive as a bit mask; the units are then
+// made of live rows only:
+//   * steering slices (lattice, ramp-hold): with R live rows a 64-lane unit holds floor(64 / R) steering columns instead of
+//     G / W, so the scenario needs ceil(G / that) units instead of W (benchmark batch: 10.7 of 16 rows live, 3.5 units
+//     instead of 4, 83 % of the wave-steps);
+//   * acceleration-axis units (tracking): unit p takes the live rows of rank p G/W .. (p+1) G/W - 1: ceil(R W / G) units.
+// Slices beyond that are empty (the wave moves on), lanes without a row or a column idle with "lost" set from the start.
+// A mask of all ones is the layout without this (IGT_DEV_FLAGS = 2097152; small batches that keep trajectories).
+// one lane per (scenario, acceleration row), 64 / G scenarios per wave: the row's (a_k, v_k) recurrence with the two verdicts that
+// read nothing else -- the statements of rollout_one (igt_fast64.h), in its order; what load_scenario reads of the scenario for
+// them (a_prev, v_0, the warm start, the refinement centre) is read per lane here
 template <int CAND>
-__device__ __forceinline__ int slice_candidate64(const KP& P, int W, int p, int lane) {
-    if (CAND == CAND_TRACK && steering_slices64<CAND>(P, W) && !(P.dev & 262144)) {
-        const int nj = P.G / W;                              // acceleration rows per unit; lane = il * G + j
-        return (p * nj + lane / P.G) * P.G + lane % P.G;
+__global__ __launch_bounds__(256) void accel_rows_kernel(KP P, int B, const double* __restrict__ x0,
+                                                         const double* __restrict__ u_prev, const uint32_t* __restrict__ flags,
+                                                         const double* __restrict__ cinf, Centre<double> cpar,
+                                                         unsigned long long* __restrict__ row_mask) {
+    const int lane = threadIdx.x & 63, lg = __ffs(P.G) - 1;                  // G is a power of two (igt_api.hip)
+    const int per_wave = 64 >> lg;                                           // scenarios per wave
+    const int wave = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int b = wave * per_wave + (lane >> lg), i = lane & (P.G - 1);
+    bool live = false;
+    if (b < B) {
+        const double a_prev = u_prev[(size_t)b * 2 + 0], df_prev = u_prev[(size_t)b * 2 + 1];
+        const double* ws = (cpar.ws && (flags[b] & 2u)) ? cpar.ws + (size_t)b * 2 * P.N : nullptr;      // load_scenario's S.ws
+        double c0 = 0.0, c2 = P.N * P.rate_a;                                                           // ... and S.cpar[0], [2]
+        if (cpar.cpar) { c0 = cpar.cpar[(size_t)b * 4 + 0]; c2 = cpar.cpar[(size_t)b * 4 + 2]; }
+        double da;
+        if (CAND == CAND_LATTICE) da = -P.rate_a + (2 * P.rate_a) * (double)i / (double)(P.G - 1);
+        else da = c0 + cand_m(i, P.G, P.refine_it == 0) * c2;
+        double a = a_prev, v = x0[(size_t)b * 7 + 5], g = -1.0e300;
+        unsigned viol = 0;
+        for (int k = 0; k < P.N; ++k) {
+            if (CAND == CAND_LATTICE) {
+                a = clampd(a + da, P.a_min, P.a_max);
+            } else {
+                double ba, bdf;
+                ramp_base<double>(ws, P.N, k, a_prev, df_prev, ba, bdf);
+                const double ta = CAND == CAND_TRACK ? track_accel_target(P, k, ba, da) : clampd(ba + da, P.a_min, P.a_max);
+                a = clampd(a + clampd(ta - a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
+            }
+            g = fmax(g, fmax(P.v_min - v, v - P.v_max));                             // mpc.py:316-317 (k < N)
+            if (k == P.N - 1) viol |= terminal_viol(P, v, a, cinf);                  // mpc.py:177-180
+            v = fma(P.dt, a, v);
+        }
+        live = !(g > P.tol) && viol == 0;
     }
-    if (steering_slices64<CAND>(P, W)) {
-        const int nj = P.G / W, jl = lane % nj, il = lane / nj, r = p * nj + jl;      // il < 64 W / G = G
-        const int j = (r & 1) ? P.G / 2 - 1 - (r >> 1) : P.G / 2 + (r >> 1);
-        return il * P.G + j;
-    }
-    return p * 64 + lane;
+    const unsigned long long m = __ballot(live);
+    if (b < B && i == 0) row_mask[b] = (m >> (lane & ~(P.G - 1))) & (P.G >= 64 ? ~0ull : ((1ull << P.G) - 1ull));
+}
+
+// launch-time bit of KP::dev (never taken from IGT_DEV_FLAGS): the masks of accel_rows_kernel sit behind the partials
+constexpr int DEV_LIVE_ROWS = 1 << 30;
+__device__ __forceinline__ const unsigned long long* live_rows_of(const KP& P, int B, int W, const double* part_J) {
+    return (P.dev & DEV_LIVE_ROWS) ? reinterpret_cast<const unsigned long long*>(part_J + (size_t)B * W) : nullptr;
 }
 
 #define IGT_SEARCH64_ARGS                                                                                            \
@@ -191,20 +238,30 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
                                               double* __restrict__ rec_vN, double* __restrict__ rec_J,
                                               uint32_t* __restrict__ rec_viol, unsigned* __restrict__ rec_count,
                                               int32_t* __restrict__ rec_b, int2* __restrict__ unit_seg,
+                                              const unsigned long long* __restrict__ row_mask = nullptr,
                                               double* __restrict__ traj = nullptr) {
     const int lane = threadIdx.x & 63;
+    const UnitLayout L = unit_layout(P, W, CAND, row_mask ? row_mask[b] : ~0ull);
+    if (p >= L.n_units) {             // the scenario's live rows fit fewer units: this slice holds nothing
+        if (lane == 0) {
+            if (VALUE) unit_seg[b * W + p] = make_int2((b * W + p) * 64, 0);
+            else { part_J[b * W + p] = 0.0; part_c[b * W + p] = -1; }
+        }
+        return;
+    }
     Scenario<double> S;
     load_scenario<double>(S, P, b, x0, u_prev, kparams, flags, obs, cpar);
     NullSink sink;
-    const int c = slice_candidate64<CAND>(P, W, p, lane);
+    __shared__ int rank2row[64];
+    rows_by_rank(L, lane, rank2row);
+    const int c = unit_candidate(P, L, p, lane, rank2row);   // -1: a lane without a candidate (rolls one, counts as lost)
     double J, sN, vN;
     unsigned viol;
     if constexpr (CAPTURE) {      // small batches: every lane's trajectory is kept for emit_gather_f64_kernel (all rows, so no
                                   // Cartesian skip; same arithmetic as below, same bits)
         CaptureSink keep{traj + (size_t)(b * W + p) * traj_unit_doubles(P.N) + lane, P.N + 1};
-        constexpr bool TAB = CAND == CAND_LATTICE || CAND == CAND_RAMP_HOLD;
-        const int njc = P.G / W;
-        if (TAB && steering_slices64<CAND>(P, W) && njc * P.N <= f64::STAB_MAX_ENTRIES && !(P.dev & 4)) {
+        const int njc = L.per;
+        if (L.kind == 2 && steer_table_fits(P, W, CAND)) {
             __shared__ double stabc[f64::STAB_MAX_ENTRIES * 3];
             f64::fill_steer_table<CAND>(P, S, njc, p, lane, P.lr_ratio, stabc);
             f64::rollout_one<CAND, HI, true, true, CaptureSink, true, true, NRK, true>(P, S, c, table, cinf, keep, J, viol, sN, vN,
@@ -216,12 +273,11 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
     } else {
     // steering slices of the families with state-independent steering: the slice's G/W steering columns are laid out in
     // LDS once per unit instead of being recomputed by each of their 64 W/G lanes at every step (igt_fast64.h)
-    constexpr bool TABULATED = CAND == CAND_LATTICE || CAND == CAND_RAMP_HOLD;
-    const int nj = P.G / W;
+    const int nj = L.per;
     // 70 % of the benchmark's scenarios: the other vehicle is out of reach over the whole horizon (or filter_preds moved it
     // away), so the unit rolls without the Cartesian rows -- a sixth of the control step's instructions
     const bool far = !(P.dev & 65536) && obstacles_out_of_reach<double>(P, S, lane);
-    if (TABULATED && steering_slices64<CAND>(P, W) && nj * P.N <= f64::STAB_MAX_ENTRIES && !(P.dev & 4)) {
+    if (L.kind == 2 && steer_table_fits(P, W, CAND)) {
         __shared__ double stab[f64::STAB_MAX_ENTRIES * 3];
         f64::fill_steer_table<CAND>(P, S, nj, p, lane, P.lr_ratio, stab);
         if (far)
@@ -269,17 +325,17 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
 // persistent waves on the per-XCD queues (search_waves), 2 or 3 per SIMD like the float kernels.  NRK = 4: the build for the
 // reference's discretisation (num_rk4_steps = 4, evaluate.py:109), NRK = 0: any n_rk4 (same arithmetic, same bits)
 template <int CAND, bool HI, bool VALUE, int NRK>
-__global__ __launch_bounds__(64) void search_f64_kernel_o2(IGT_SEARCH64_ARGS) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void search_f64_kernel_o2(IGT_SEARCH64_ARGS) {
     search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
         search_unit64<CAND, HI, VALUE, NRK>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN,
-                                       rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg);
+                                       rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg, live_rows_of(P, B, W, part_J));
     });
 }
 template <int CAND, bool HI, bool VALUE, int NRK>      // held to 256 registers for the tracking family (see search_fast_kernel_o2w)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void search_f64_kernel_o2w(IGT_SEARCH64_ARGS) {
     search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
         search_unit64<CAND, HI, VALUE, NRK>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN,
-                                       rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg);
+                                       rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg, live_rows_of(P, B, W, part_J));
     });
 }
 // small batches (captures_trajectories): the same search, every unit also leaves its 64 trajectories in `traj`
@@ -288,16 +344,16 @@ __global__ __launch_bounds__(64) void search_f64_kernel_cap(IGT_SEARCH64_ARGS, d
     if (queues == 0) {      // every unit has a wave of its own (search_is_static): no queues, no counters
         search_unit64<CAND, false, VALUE, 4, true>(P, W, (int)(blockIdx.x / (unsigned)W), (int)(blockIdx.x % (unsigned)W), x0, u_prev,
                                                    kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN, rec_vN, rec_J,
-                                                   rec_viol, rec_count, rec_b, unit_seg, traj);
+                                                   rec_viol, rec_count, rec_b, unit_seg, nullptr, traj);
         return;
     }
     search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
         search_unit64<CAND, false, VALUE, 4, true>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c,
-                                                   rec_sN, rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg, traj);
+                                                   rec_sN, rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg, nullptr, traj);
     });
 }
 // one 64-thread block per scenario: final arg-min over the W partials, then the winner's trajectory copied out of the unit
-// that rolled it.  Which lane that was is asked of slice_candidate64 itself, so the two cannot drift apart.
+// that rolled it.  Which lane that was is asked of unit_candidate itself, so the two cannot drift apart.
 template <int CAND>
 __global__ __launch_bounds__(64) void emit_gather_f64_kernel(KP P, int B, int W, const double* __restrict__ part_J,
                                                              const int32_t* __restrict__ part_c,
@@ -320,7 +376,8 @@ __global__ __launch_bounds__(64) void emit_gather_f64_kernel(KP P, int B, int W,
     const int N1 = P.N + 1, nx = 7 * N1, nu = 2 * P.N;
     double* xo = x_out + (size_t)b * nx;
     double* uo = u_out + (size_t)b * nu;
-    const unsigned long long holder = __ballot(c >= 0 && slice_candidate64<CAND>(P, W, pw, lane) == c);
+    const UnitLayout L = unit_layout(P, W, CAND, ~0ull);      // batches that keep trajectories run the full layout
+    const unsigned long long holder = __ballot(c >= 0 && unit_candidate(P, L, pw, lane, nullptr) == c);
     if (c < 0 || holder == 0ull) {     // is_opt False (mpc.py:402-406): no trajectory
         for (int i = lane; i < nx; i += 64) xo[i] = (double)NAN;
         for (int i = lane; i < nu; i += 64) uo[i] = (double)NAN;
@@ -335,7 +392,7 @@ template <int CAND, bool HI, bool VALUE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void search_f64_kernel_o3(IGT_SEARCH64_ARGS) {
     search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
         search_unit64<CAND, HI, VALUE>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN,
-                                       rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg);
+                                       rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg, live_rows_of(P, B, W, part_J));
     });
 }
 #endif
@@ -543,6 +600,14 @@ bool search_is_static(const KP& P, int B, const SolveArgs<double>& A) {
     return captures_trajectories(P, A) && (size_t)B * (P.C / 64) <= (size_t)A.n_cu * 4 && !(P.dev & (256 | 1048576));
 }
 
+// Whether the search runs on units made of live acceleration rows only (accel_rows_kernel; unit_layout).  Not for batches that
+// keep trajectories: their units all run at once, fewer of them would not shorten the solve, and the extra launch would.
+static bool packs_live_rows(const KP& P, int B, const SolveArgs<double>& A) {
+    const int W = P.C / 64;
+    return A.row_mask && P.cand_mode != CAND_TABLE && P.G <= 64 && P.G * P.G == P.C && W * 64 == P.C && P.G % W == 0 &&
+           !(P.dev & (1 | 1024 | 2048 | 2097152)) && !captures_trajectories(P, A);
+}
+
 // float64 search: persistent waves on the per-XCD queues, one 64-candidate unit at a time
 template <int CAND, bool HI, bool VALUE>
 static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A, hipStream_t st) {
@@ -568,9 +633,22 @@ static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A
                            A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b, A.unit_seg, A.traj);
         return hipGetLastError();
     }
+    // the live-row masks live behind the partials (part_J[B W ..]): no further kernel argument -- the search kernels spill
+    // scalar registers as it is, and every one more shows up as v_readlane in the control-step loop
+    KP Pr = P;
+    const unsigned long long* rows = nullptr;
+    if constexpr (CAND != CAND_TABLE) {
+        if (packs_live_rows(P, B, A)) {
+            rows = reinterpret_cast<const unsigned long long*>(A.part_J + (size_t)B * W);
+            const int per_block = 4 * (64 / P.G);                      // scenarios per 256-thread block
+            hipLaunchKernelGGL((accel_rows_kernel<CAND>), dim3((B + per_block - 1) / per_block), dim3(256), 0, st, P, B, A.x0, A.u_prev,
+                               A.flags, A.cinf, A.centre(), const_cast<unsigned long long*>(rows));
+            Pr.dev |= DEV_LIVE_ROWS;
+        }
+    }
     if (search_builds_queues(P, B, A)) {                     // small batches: longest units first
         hipLaunchKernelGGL(build_queues_kernel<double>, dim3(8), dim3(QB_THREADS), 0, st, P, B, W, A.x0, A.kparams,
-                           A.queue_order, order_stride, A.work_counter);
+                           A.queue_order, order_stride, A.work_counter, rows);
         order = A.queue_order;
     }
     if (!HI && captures_trajectories(P, A)) {
@@ -581,7 +659,7 @@ static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A
     }
 #if IGT_DEV_KERNELS
     if (o3)
-        hipLaunchKernelGGL((search_f64_kernel_o3<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter, order,
+        hipLaunchKernelGGL((search_f64_kernel_o3<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, Pr, B, W, 8, A.work_counter, order,
                            order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c,
                            A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b, A.unit_seg);
     else
@@ -591,7 +669,7 @@ static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A
         constexpr int NRK4 = HI ? 0 : 4;
         const bool rk4 = NRK4 == 4 && P.n_rk4 == 4;
 #define IGT_LAUNCH_S64(KERNEL, NRK_)                                                                                          \
-        hipLaunchKernelGGL((KERNEL<CAND, HI, VALUE, NRK_>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter, order,     \
+        hipLaunchKernelGGL((KERNEL<CAND, HI, VALUE, NRK_>), dim3(grid), dim3(64), 0, st, Pr, B, W, 8, A.work_counter, order,    \
                            order_stride, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, \
                            A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b, A.unit_seg)
         if constexpr (CAND == CAND_TRACK) {

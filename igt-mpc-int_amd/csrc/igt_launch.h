@@ -50,6 +50,7 @@ struct SolveArgs {   // all device pointers
     int2* unit_seg;                 // double path: [B, C/64] (first entry, count) of each unit's entries in the compact list
     double* prune_thr;              // double path: [B] cost above which an entry cannot win (value_bound_kernel)
     unsigned* live_idx;             // double path: entries left for the network after value_prune_kernel
+    unsigned long long* row_mask;   // double path: [B] live acceleration rows of the generated families (accel_rows_kernel)
     double* traj;                   // double path, small batches: [B C/64][9][N+1][64] kept by the search pass (null: none)
 };
 

@@ -538,12 +538,13 @@ def test_value_net_with_ramp_hold_refinement_f64(igt, golden_dir):
 def test_production_kernel_switches_change_nothing(igt, dtype, cand, monkeypatch):
     """The A/B switches of the production kernels (IGT_DEV_FLAGS; VERDICT r2: "untested surface") only change HOW the work
     is laid out -- candidate slices in index order (1), no early exit (2), no steering table (4), no longest-first queues
-    (16), no stealing between the XCDs' queues (512), tracking units cut along the steering axis (262144) -- never the
+    (16), no stealing between the XCDs' queues (512), tracking units cut along the steering axis (262144), units made of all
+    acceleration rows instead of the live ones (2097152) -- never the
     answer: every one of them gives the default solve bit for bit, on a batch small enough to take the queue builder."""
     npdt = np.float64 if dtype == 'f64' else np.float32
     b = _batch(1536, npdt)
     outs = {}
-    for flag in (0, 1, 2, 4, 16, 512, 262144, 1 | 2 | 4 | 16 | 512):
+    for flag in (0, 1, 2, 4, 16, 512, 262144, 2097152, 1 | 2 | 4 | 16 | 512, 4 | 2097152):
         monkeypatch.setenv('IGT_DEV_FLAGS', str(flag))
         with igt.BatchSolver(dtype=dtype, cand_mode=cand) as s:
             s.set_cinf(*_cinf())
@@ -553,6 +554,44 @@ def test_production_kernel_switches_change_nothing(igt, dtype, cand, monkeypatch
     for flag, o in outs.items():
         for k in ('x', 'u', 'cost', 'argmin', 'status'):
             assert np.array_equal(o[k], outs[0][k], equal_nan=True), (flag, k)
+
+
+@pytest.mark.parametrize('cand,N,C,B', [('lattice', 20, 256, 4096), ('ramp_hold', 20, 256, 4096), ('track', 20, 256, 4096),
+                                        ('lattice', 20, 256, 8200), ('track', 40, 256, 1500), ('lattice', 40, 256, 1500),
+                                        ('lattice', 20, 1024, 700), ('track', 12, 1024, 700), ('ramp_hold', 20, 64, 700)])
+def test_units_of_live_acceleration_rows_change_nothing(igt, golden_dir, cand, N, C, B, monkeypatch):
+    """The f64 search first rolls the G acceleration recurrences of every scenario (accel_rows_kernel) and builds its units from
+    the rows that hold the speed box and the terminal set -- a failing row is infeasible in all of its columns, so it cannot
+    win (igt_kernels_f64.hip "Acceleration rows that cannot win").  With IGT_DEV_FLAGS = 2097152 every row is rolled as
+    before: the solve must be the same bit for bit -- with and without the queue builder (B = 8200 has none), at both horizons,
+    with 1, 4 and 16 units per scenario, with warm starts and a refinement pass, and under the value-network cost."""
+    b = _batch(B, np.float64, N=N)
+    rng = np.random.default_rng(11)
+    flags, u_prev, u_ws = b['flags'], b['u_prev'], None
+    if cand != 'lattice':      # two thirds of the scenarios carry a warm start (its base sequence moves the rows' recurrences)
+        prev = O.candidates_lattice(b['u_prev'], O.Params(N=N))[np.arange(B), (np.arange(B) * 37) % 256]
+        u_ws = np.ascontiguousarray(O.shift_controls(prev))
+        u_prev = np.ascontiguousarray(prev[:, :, 0])
+        flags = flags | np.where(np.arange(B) % 3 != 0, 2, 0).astype(np.uint32)
+    for cost_mode in ('progress', 'value_net'):
+        if cost_mode == 'value_net' and (C != 256 or B > 4096):
+            continue
+        outs = []
+        net = dict(layers=_nets(golden_dir)[1], Wn=np.eye(6) + 0.05 * rng.normal(size=(6, 6)), mu_f=np.zeros(6), sigma_t=2.0, mu_t=0.3)
+        for flag in ('0', '2097152'):
+            monkeypatch.setenv('IGT_DEV_FLAGS', flag)
+            with igt.BatchSolver(N=N, C=C, dtype='f64', cand_mode=cand, cost_mode=cost_mode,
+                                 refine_iters=1 if cand == 'ramp_hold' else 0) as s:
+                s.set_cinf(*_cinf())
+                extra = ()
+                if cost_mode == 'value_net':
+                    s.set_value_net(**net)
+                    extra = (b['tv_sv'], b['enc'])
+                outs.append(s.solve(b['x0'], u_prev, b['kparams'], flags, b['obs_xy'], *extra, u_ws=u_ws))
+        monkeypatch.delenv('IGT_DEV_FLAGS')
+        assert (outs[0]['status'] == 0).mean() > 0.3
+        for k in ('x', 'u', 'cost', 'argmin', 'status'):
+            assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), (cost_mode, k)
 
 
 @pytest.mark.parametrize('cand,N', [('lattice', 20), ('track', 20), ('ramp_hold', 20), ('track', 40), ('table', 20)])
