@@ -316,7 +316,8 @@ __device__ __forceinline__ void terminal_viol2(const KP& P, const double (&v)[2]
 // ---------------------------------------------------------------------------------------
 // one rollout pass over NC candidates of one scenario
 // ---------------------------------------------------------------------------------------
-constexpr int STEER_TABLE_MAX_ENTRIES = 320;     // steering columns x N of one float64 search unit's LDS table (igt_fast64.h)
+constexpr int STEER_TABLE_MAX_ENTRIES = 360;     // steering columns x N of one float64 search unit's LDS table (igt_fast64.h):
+                                                 // 4 x 20 in the plain layout, up to 17 x 20 with 4 live rows (igt_kernels_common.h)
 
 template <typename T>
 struct Scenario {           // wave-uniform inputs of one scenario

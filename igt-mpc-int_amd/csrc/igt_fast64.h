@@ -314,15 +314,15 @@ __device__ __forceinline__ void slip_trig(const KP& P, double lr_ratio, double d
 // of all entries in parallel), with the same functions the untabulated roll-out calls: the same bits.
 constexpr int STAB_MAX_ENTRIES = STEER_TABLE_MAX_ENTRIES;        // columns x N per unit (C = 256: 4 x 20, N = 40: 160; C = 64: 8 x 40)
 template <int CAND>
-__device__ __forceinline__ void fill_steer_table(const KP& P, const Scenario<double>& S, int nj, int p, int lane,
+__device__ __forceinline__ void fill_steer_table(const KP& P, const Scenario<double>& S, int nj, int r_first, int lane,
                                                  double lr_ratio, double* __restrict__ stab) {
-    if (lane < nj) {
-        const int r = p * nj + lane;                                              // the last unit may hold fewer than nj columns
+    if (lane < nj) {                                                              // nj columns from rank r_first on (< G)
+        const int r = r_first + lane;
         const int j = (r & 1) ? P.G / 2 - 1 - (r >> 1) : P.G / 2 + (r >> 1);      // unit_candidate's column order
-        const double ddf = r < P.G ? steer_column<CAND>(P, S, j) : 0.0;
+        const double ddf = steer_column<CAND>(P, S, j);
         double df = S.df_prev;
         for (int k = 0; k < P.N; ++k) {
-            df = r < P.G ? steer_next<CAND>(P, S, k, ddf, df) : 0.0;
+            df = steer_next<CAND>(P, S, k, ddf, df);
             stab[(k * nj + lane) * 3] = df;
         }
     }

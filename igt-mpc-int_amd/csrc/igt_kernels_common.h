@@ -85,7 +85,8 @@ __device__ __forceinline__ int queue_scenario(int q, int j) { return 8 * j + ((q
 //   * a scenario that meets its arc within the horizon rolls the long sub-step variants (about 1.9x per step).
 // ---- units of the float64 search (igt_kernels_f64.hip: "Acceleration rows that cannot win") ----
 struct UnitLayout {
-    int kind;                       // 0: 64 candidates in index order, 1: acceleration-axis units, 2: steering slices
+    int kind;                       // 0: 64 candidates in index order, 1: acceleration-axis units, 2: whole steering columns per
+                                    // unit, 3: 64 live candidates per unit in column-major order (columns may straddle units)
     int per;                        // kind 1: rows per unit, kind 2: steering columns per unit
     int n_units, R;
     unsigned long long mask;        // live acceleration rows
@@ -95,7 +96,7 @@ struct UnitLayout {
 __device__ __forceinline__ int small_div(int x, int d) {
     return (int)(((float)x + 0.5f) * __builtin_amdgcn_rcpf((float)d));
 }
-// whether the steering table of a slice fits LDS with the layout's own G / W columns (then `per` is kept within it)
+// whether the steering table of a slice fits LDS with the layout's own G / W columns (then the live-row layouts keep within it)
 __device__ __forceinline__ bool steer_table_fits(const KP& P, int W, int cand) {
     return (cand == CAND_LATTICE || cand == CAND_RAMP_HOLD) && (P.G / W) * P.N <= STEER_TABLE_MAX_ENTRIES && !(P.dev & 4);
 }
@@ -111,15 +112,34 @@ __device__ __forceinline__ UnitLayout unit_layout(const KP& P, int W, int cand, 
         L.n_units = (L.R + nj - 1) / nj;                     // nj is a power of two as well
         return L;
     }
+    const bool table = steer_table_fits(P, W, cand);
+    // 64 live candidates per unit, column by column from the centre outwards: a unit touches at most floor(63 / R) + 2 columns
+    if (L.R > 0 && !(P.dev & 4194304) && (!table || (small_div(63, L.R) + 2) * P.N <= STEER_TABLE_MAX_ENTRIES)) {
+        L.kind = 3; L.per = 0;
+        L.n_units = __builtin_amdgcn_readfirstlane((P.G * L.R + 63) >> 6);
+        return L;
+    }
     L.kind = 2;
     int per = L.R > 0 ? small_div(64, L.R) : P.G;
     if (per > P.G) per = P.G;
-    if (steer_table_fits(P, W, cand)) { const int cap = small_div(STEER_TABLE_MAX_ENTRIES, P.N); if (per > cap) per = cap; }
+    if (table) { const int cap = small_div(STEER_TABLE_MAX_ENTRIES, P.N); if (per > cap) per = cap; }
     // the float detour leaves these in vector registers although they are the same on every lane: back to scalars, or the
     // stride of the steering table is recomputed on the vector ALU at every control step
     L.per = __builtin_amdgcn_readfirstlane(per);
     L.n_units = __builtin_amdgcn_readfirstlane(L.R > 0 ? small_div(P.G + per - 1, per) : 0);
     return L;
+}
+// the steering columns (ranks, centre outwards) unit p touches: first and how many
+__device__ __forceinline__ void unit_columns(const KP& P, const UnitLayout& L, int p, int& r_first, int& ncol) {
+    if (L.kind == 3) {
+        r_first = __builtin_amdgcn_readfirstlane(small_div(64 * p, L.R));
+        int r_last = __builtin_amdgcn_readfirstlane(small_div(64 * p + 63, L.R));
+        if (r_last > P.G - 1) r_last = P.G - 1;
+        ncol = r_last - r_first + 1;
+    } else {
+        r_first = p * L.per;
+        ncol = P.G - r_first < L.per ? P.G - r_first : L.per;
+    }
 }
 // rank -> row of the live acceleration rows, laid out in LDS by the unit's wave (one workgroup = one wave): lane i, if row i is
 // live, stores i at the number of live rows below it
@@ -129,19 +149,33 @@ __device__ __forceinline__ void rows_by_rank(const UnitLayout& L, int lane, int*
     }
     __syncthreads();
 }
-// candidate of lane `lane` of unit p, or -1 for a lane that holds none (rank2row: rows_by_rank's table, or null: searched)
-__device__ __forceinline__ int unit_candidate(const KP& P, const UnitLayout& L, int p, int lane, const int* __restrict__ rank2row) {
+// candidate of lane `lane` of unit p, or -1 for a lane that holds none (rank2row: rows_by_rank's table, or null: searched);
+// col_off: the lane's steering column, counted from the unit's first (steering slices)
+__device__ __forceinline__ int unit_candidate(const KP& P, const UnitLayout& L, int p, int lane, const int* __restrict__ rank2row,
+                                              int* col_off = nullptr) {
     if (L.kind == 0) return p * 64 + lane;
     const int lg = __ffs(P.G) - 1;                           // G is a power of two
-    int rank, j;
+    int rank, j, off = 0;
     if (L.kind == 1) {                                       // lane = il * G + j
         rank = p * L.per + (lane >> lg);
         j = lane & (P.G - 1);
-    } else {                                                 // lane = il * per + jl; column rank r, handed out from the centre outwards
-        const int il = small_div(lane, L.per), r = p * L.per + (lane - il * L.per);
-        rank = (r < P.G) ? il : L.R;
-        j = (r & 1) ? P.G / 2 - 1 - (r >> 1) : P.G / 2 + (r >> 1);
+    } else {
+        int r;
+        if (L.kind == 3) {                                   // candidate number g = r R + q of the scenario's live ones
+            const int g = 64 * p + lane;
+            r = small_div(g, L.R);
+            rank = g - r * L.R;
+            off = r - small_div(64 * p, L.R);
+        } else {                                             // lane = il * per + jl
+            const int il = small_div(lane, L.per);
+            off = lane - il * L.per;
+            r = p * L.per + off;
+            rank = il;
+        }
+        if (r >= P.G) rank = L.R;
+        j = (r & 1) ? P.G / 2 - 1 - (r >> 1) : P.G / 2 + (r >> 1);      // column rank r, handed out from the centre outwards
     }
+    if (col_off) *col_off = off;
     if (rank >= L.R) return -1;
     int row;
     if (rank2row) row = rank2row[rank];

@@ -254,18 +254,19 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
     NullSink sink;
     __shared__ int rank2row[64];
     rows_by_rank(L, lane, rank2row);
-    const int c = unit_candidate(P, L, p, lane, rank2row);   // -1: a lane without a candidate (rolls one, counts as lost)
+    int col = 0, r_first = 0, nj = 1;                        // steering slices: the unit's columns, the lane's among them
+    const int c = unit_candidate(P, L, p, lane, rank2row, &col);   // -1: a lane without a candidate (rolls one, counts as lost)
+    if (L.kind >= 2) unit_columns(P, L, p, r_first, nj);
     double J, sN, vN;
     unsigned viol;
     if constexpr (CAPTURE) {      // small batches: every lane's trajectory is kept for emit_gather_f64_kernel (all rows, so no
                                   // Cartesian skip; same arithmetic as below, same bits)
         CaptureSink keep{traj + (size_t)(b * W + p) * traj_unit_doubles(P.N) + lane, P.N + 1};
-        const int njc = L.per;
-        if (L.kind == 2 && steer_table_fits(P, W, CAND)) {
+        if (L.kind >= 2 && steer_table_fits(P, W, CAND)) {
             __shared__ double stabc[f64::STAB_MAX_ENTRIES * 3];
-            f64::fill_steer_table<CAND>(P, S, njc, p, lane, P.lr_ratio, stabc);
+            f64::fill_steer_table<CAND>(P, S, nj, r_first, lane, P.lr_ratio, stabc);
             f64::rollout_one<CAND, HI, true, true, CaptureSink, true, true, NRK, true>(P, S, c, table, cinf, keep, J, viol, sN, vN,
-                                                                                       stabc + (lane % njc) * 3, njc * 3);
+                                                                                       stabc + col * 3, nj * 3);
             __syncthreads();
         } else {
             f64::rollout_one<CAND, HI, true, true, CaptureSink, true, false, NRK, true>(P, S, c, table, cinf, keep, J, viol, sN, vN);
@@ -273,19 +274,18 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
     } else {
     // steering slices of the families with state-independent steering: the slice's G/W steering columns are laid out in
     // LDS once per unit instead of being recomputed by each of their 64 W/G lanes at every step (igt_fast64.h)
-    const int nj = L.per;
     // 70 % of the benchmark's scenarios: the other vehicle is out of reach over the whole horizon (or filter_preds moved it
     // away), so the unit rolls without the Cartesian rows -- a sixth of the control step's instructions
     const bool far = !(P.dev & 65536) && obstacles_out_of_reach<double>(P, S, lane);
-    if (L.kind == 2 && steer_table_fits(P, W, CAND)) {
+    if (L.kind >= 2 && steer_table_fits(P, W, CAND)) {
         __shared__ double stab[f64::STAB_MAX_ENTRIES * 3];
-        f64::fill_steer_table<CAND>(P, S, nj, p, lane, P.lr_ratio, stab);
+        f64::fill_steer_table<CAND>(P, S, nj, r_first, lane, P.lr_ratio, stab);
         if (far)
             f64::rollout_one<CAND, HI, true, true, NullSink, true, true, NRK, false>(P, S, c, table, cinf, sink, J, viol, sN, vN,
-                                                                                     stab + (lane % nj) * 3, nj * 3);
+                                                                                     stab + col * 3, nj * 3);
         else
             f64::rollout_one<CAND, HI, true, true, NullSink, true, true, NRK, true>(P, S, c, table, cinf, sink, J, viol, sN, vN,
-                                                                                    stab + (lane % nj) * 3, nj * 3);
+                                                                                    stab + col * 3, nj * 3);
         __syncthreads();                                  // the next unit of this wave rewrites the table
     } else if (far) {
         f64::rollout_one<CAND, HI, true, true, NullSink, true, false, NRK, false>(P, S, c, table, cinf, sink, J, viol, sN, vN);

@@ -579,7 +579,7 @@ def test_units_of_live_acceleration_rows_change_nothing(igt, golden_dir, cand, N
             continue
         outs = []
         net = dict(layers=_nets(golden_dir)[1], Wn=np.eye(6) + 0.05 * rng.normal(size=(6, 6)), mu_f=np.zeros(6), sigma_t=2.0, mu_t=0.3)
-        for flag in ('0', '2097152'):
+        for flag in ('0', '2097152', '4194304'):      # live rows, 64 per unit; all rows; live rows in whole columns
             monkeypatch.setenv('IGT_DEV_FLAGS', flag)
             with igt.BatchSolver(N=N, C=C, dtype='f64', cand_mode=cand, cost_mode=cost_mode,
                                  refine_iters=1 if cand == 'ramp_hold' else 0) as s:
@@ -593,6 +593,7 @@ def test_units_of_live_acceleration_rows_change_nothing(igt, golden_dir, cand, N
         assert (outs[0]['status'] == 0).mean() > 0.3
         for k in ('x', 'u', 'cost', 'argmin', 'status'):
             assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), (cost_mode, k)
+            assert np.array_equal(outs[0][k], outs[2][k], equal_nan=True), (cost_mode, k)
 
 
 @pytest.mark.parametrize('cand,N', [('lattice', 20), ('track', 20), ('ramp_hold', 20), ('track', 40), ('table', 20)])

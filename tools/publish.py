@@ -21,7 +21,8 @@ for k in ('f64_b4096', 'f64_track_b4096', 'f64_b65536', 'f32_b4096', 'f32_gt1_b6
     cp(f'{tag}_{k}/summary.json', f'{rnd}_pmc_{k}.json')
     st = glob.glob(os.path.join(G, f'{tag}_{k}', 'stats', '**', '*kernel_stats.csv'), recursive=True)
     if st:
-        shutil.copy(st[0], os.path.join(P, f'{rnd}_kernel_stats_{k}.csv')); print('published', f'{rnd}_kernel_stats_{k}.csv')
+        newest = max(st, key=os.path.getmtime)      # gpurun_out/ accumulates the runs of a session: rocprofv3 names its files by pid
+        shutil.copy(newest, os.path.join(P, f'{rnd}_kernel_stats_{k}.csv')); print('published', f'{rnd}_kernel_stats_{k}.csv')
 # the literal-mapping lines of the probe, on their own
 fp = os.path.join(G, f'{tag}_f64_probe.txt')
 if os.path.exists(fp):
