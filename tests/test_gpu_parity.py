@@ -558,13 +558,14 @@ def test_production_kernel_switches_change_nothing(igt, dtype, cand, monkeypatch
 
 @pytest.mark.parametrize('cand,N,C,B', [('lattice', 20, 256, 4096), ('ramp_hold', 20, 256, 4096), ('track', 20, 256, 4096),
                                         ('lattice', 20, 256, 8200), ('track', 40, 256, 1500), ('lattice', 40, 256, 1500),
-                                        ('lattice', 20, 1024, 700), ('track', 12, 1024, 700), ('ramp_hold', 20, 64, 4500)])
+                                        ('lattice', 20, 1024, 700), ('track', 12, 1024, 700), ('ramp_hold', 20, 64, 4500),
+                                        ('lattice', 12, 4096, 200), ('track', 8, 4096, 120)])
 def test_units_of_live_acceleration_rows_change_nothing(igt, golden_dir, cand, N, C, B, monkeypatch):
     """The f64 search first rolls the G acceleration recurrences of every scenario (accel_rows_kernel) and builds its units from
     the rows that hold the speed box and the terminal set -- a failing row is infeasible in all of its columns, so it cannot
     win (igt_kernels_f64.hip "Acceleration rows that cannot win").  With IGT_DEV_FLAGS = 2097152 every row is rolled as
     before: the solve must be the same bit for bit -- with and without the queue builder (B = 8200 has none), at both horizons,
-    with 1, 4 and 16 units per scenario, with warm starts and a refinement pass, and under the value-network cost.  (Batches of
+    with 1, 4, 16 and 64 units per scenario, with warm starts and a refinement pass, and under the value-network cost.  (Batches of
     up to two rounds of units -- 1024 scenarios at 256 candidates -- keep the plain layout: every size here is above that.)"""
     b = _batch(B, np.float64, N=N)
     rng = np.random.default_rng(11)
