@@ -11,11 +11,13 @@ os.environ['IGT_DEV_FLAGS'] = str(256 | int(os.environ.get('IGT_DEV_FLAGS', '0')
 os.environ['IGT_DEV_TRACE'] = path
 import torch
 from igtmpc import BatchSolver
+from igtmpc.cinf import cinf_halfplanes
 from igtmpc.scenarios import make_batch
 DT = os.environ.get('IGT_PROBE_DTYPE', 'f64')
 b = make_batch(B, dtype=np.float32 if DT == 'f32' else np.float64)
 args = [torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda() for a in (b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy'])]
 with BatchSolver(dtype=DT) as s:
+    s.set_cinf(*cinf_halfplanes())           # the benchmark's configuration (bench.py): terminal set on
     for _ in range(3):
         s.solve(*args)
     torch.cuda.synchronize()
