@@ -1,6 +1,9 @@
 // igt_kernels_f64.hip -- gfx950 kernels of the float64 entry points (the reference's precision) and their launchers:
-//   search_f64_kernel_*   persistent waves, one 64-candidate steering slice of one scenario per unit (igt_fast64.h)
+//   search_f64_kernel_*   persistent waves, one unit -- 64 candidates of one scenario -- at a time (igt_fast64.h); _cap: small
+//                         batches, every unit also keeps its 64 trajectories
+//   accel_rows_kernel     ahead of the search (batches above 1024 scenarios): the acceleration rows that can still win
 //   emit_f64_kernel       one lane per scenario: the winner re-rolled with the same arithmetic -> x*[7,N+1], u*[2,N]
+//   emit_gather_f64_kernel   small batches: the winner's trajectory copied out of the unit that rolled it
 //   rollout_all_f64_kernel   debug / parity: every candidate's trajectory, cost and verdict bits
 //   search_kernel / emit_kernel / rollout_all_kernel<ExactStepper<double>>   the oracle's operation order (IGT_DEV_FLAGS=1024)
 //   search_literal_f64_kernel   the literal north_star mapping, a measurement variant (IGT_DEV_FLAGS=2048)
@@ -147,11 +150,8 @@ __global__ __launch_bounds__(256) void rollout_all_kernel(KP P, int B, const T* 
 // ---------------------------------------------------------------------------------------
 // Generated G x G families with W * 64 == C and W | G: unit p takes G/W STEERING values (all G accelerations), handed out
 // from the centre of the range outwards, as the float path does with its 128-candidate slices -- the extreme-steering
-// units fail as a whole within a few steps and leave through the early exit.  Otherwise: chunks of 64 in index order.
-template <int CAND>
-__device__ __forceinline__ bool steering_slices64(const KP& P, int W) {
-    return CAND != CAND_TABLE && P.G * P.G == P.C && W * 64 == P.C && P.G % W == 0 && !(P.dev & 1);
-}
+// units fail as a whole within a few steps and leave through the early exit.  Otherwise: chunks of 64 in index order
+// (igt_kernels_common.h unit_layout / unit_candidate).
 // The tracking family's steering is a feedback on the rolled state: its candidates hardly ever fail on |e_y|, they fail on
 // what the ACCELERATION profile decides (collision, speed box, terminal set), so its units are cut along the acceleration
 // axis instead -- unit p takes G/W consecutive acceleration offsets with all G steering offsets (tools/death_steps_track.py:
@@ -163,12 +163,15 @@ __device__ __forceinline__ bool steering_slices64(const KP& P, int W) {
 // G columns whatever the steering does.  accel_rows_kernel rolls the G scalar recurrences of a scenario ahead of the search
 // (the same expressions as rollout_one, so the same bits) and leaves the rows that survive as a bit mask; the units are then
 // made of live rows only:
-//   * steering slices (lattice, ramp-hold): with R live rows a 64-lane unit holds floor(64 / R) steering columns instead of
-//     G / W, so the scenario needs ceil(G / that) units instead of W (benchmark batch: 10.7 of 16 rows live, 3.5 units
-//     instead of 4, 83 % of the wave-steps);
+//   * steering slices (lattice, ramp-hold): the scenario's G R live candidates are numbered column by column from the centre
+//     of the steering range outwards and unit p takes numbers 64 p .. 64 p + 63 -- ceil(G R / 64) units instead of W, a column
+//     may straddle two of them (benchmark batch: 10.7 of 16 rows live, 3.1 units instead of 4, 77 % of the wave-steps).  Where
+//     the unit's steering table would not hold the floor(63 / R) + 2 columns such a unit can touch -- or with
+//     IGT_DEV_FLAGS = 4194304 -- a unit holds floor(64 / R) whole columns instead (3.5 units, 83 %);
 //   * acceleration-axis units (tracking): unit p takes the live rows of rank p G/W .. (p+1) G/W - 1: ceil(R W / G) units.
-// Slices beyond that are empty (the wave moves on), lanes without a row or a column idle with "lost" set from the start.
-// A mask of all ones is the layout without this (IGT_DEV_FLAGS = 2097152; small batches that keep trajectories).
+// Slices beyond that are empty (the wave moves on), lanes without a candidate idle with "lost" set from the start.
+// A mask of all ones is the layout without this (IGT_DEV_FLAGS = 2097152; small batches, packs_live_rows).
+//
 // one lane per (scenario, acceleration row), 64 / G scenarios per wave: the row's (a_k, v_k) recurrence with the two verdicts that
 // read nothing else -- the statements of rollout_one (igt_fast64.h), in its order; what load_scenario reads of the scenario for
 // them (a_prev, v_0, the warm start, the refinement centre) is read per lane here
