@@ -434,6 +434,7 @@ def main():
             sv = BatchSolver(N=N, C=C, n_obs=1, device=dev, dtype=dtype, cost_mode='value_net' if gt else 'progress',
                              cand_mode=cand_mode)
             sv.set_cinf(*cinf_halfplanes(dt=sv.params.dt, jerk=sv.params.jerk_limit))
+            sv.set_concurrency(F)                         # F solves in flight: the search kernels share the wave slots in pairs
             if gt:
                 sv.set_value_net(layers)
             solvers.append(sv)
@@ -525,7 +526,8 @@ def main():
             for sv in solvers:
                 sv.set_profiling(False)
             lane_s, lane_e = float(np.mean(ls)), float(np.mean(le))
-        # (2) one solve at a time
+        # (2) one solve at a time (with the whole device to itself: two waves per SIMD again)
+        solver.set_concurrency(1)
         solver.set_profiling(True)
         ks, ke = [], []
         for _ in range(max(8, min(steps, 50))):

@@ -58,6 +58,7 @@ struct igt_handle {
     bool ev_recorded;
     int nc;
     int n_cu;              // compute units of the device (sizes the persistent search grid)
+    int concurrency;       // solves the caller keeps in flight on the device (igt_set_concurrency)
     void* comm;            // RCCL communicator of igt_comm_init (null: none)
     int comm_world, comm_rank;
     int32_t comm_B_local;  // shard size of the communicator's first all-gather (0 = none yet); later calls must match
@@ -341,6 +342,7 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
         const bool trace = (h->kp.dev & 256) != 0;      // developer trace: 32 B per unit behind the counters
         A.work_counter = wa.take<unsigned>(1024 + (trace ? (size_t)((B + 7) / 8) * 8 * Wk * 8 : 0));
         A.n_cu = h->n_cu;
+        A.waves_per_simd = h->concurrency >= 3 ? 1 : 2;      // two solves in flight do not overlap on this runtime (igtmpc.h)
         // small batches: the search pass leaves horizon checkpoints, emit rolls the winner's four quarters at once
         A.ckpt = use_ckpt ? wa.take<double>((size_t)(ck_parts - 1) * B * Wk * igt::SEG_UNIT_DOUBLES) : nullptr;
         A.ck_parts = ck_parts;
@@ -722,6 +724,7 @@ int igt_create(const igt_params* p, int device, igt_handle** out) {
     }
     while ((p->C / 64) % h->nc) h->nc /= 2;
     h->n_cu = 256;
+    h->concurrency = 1;
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) h->n_cu = v; }
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(IGT_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
@@ -1055,6 +1058,13 @@ int igt_allgather_controls_f32(igt_handle* h, int32_t B_local, const float* u_ou
 }
 int igt_allgather_controls_f64(igt_handle* h, int32_t B_local, const double* u_out, double* u0_all, void* stream) {
     return allgather_impl<double>(h, B_local, u_out, u0_all, stream);
+}
+
+int igt_set_concurrency(igt_handle* h, int32_t solves_in_flight) {
+    if (!h) return fail(IGT_E_INVALID, "null handle");
+    if (solves_in_flight < 1 || solves_in_flight > 64) return fail(IGT_E_INVALID, "solves_in_flight must lie in [1, 64]");
+    h->concurrency = solves_in_flight;
+    return IGT_OK;
 }
 
 int igt_set_profiling(igt_handle* h, int enable) {

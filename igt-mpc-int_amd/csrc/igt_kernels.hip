@@ -566,7 +566,7 @@ static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>&
     // ahead on big batches in round 1; with the sub-step variants unrolled it spills 228 B/lane and is behind at every
     // size but one (B = 32 768: +0.7 %) -- it stays selectable for A/B runs (IGT_DEV_FLAGS = 32)
     const bool o3 = IGT_DEV_KERNELS && (P.dev & 32) != 0;
-    const size_t slots = (size_t)A.n_cu * 4 * (o3 ? 3 : 2);
+    const size_t slots = (size_t)A.n_cu * 4 * (o3 ? 3 : (A.waves_per_simd == 1 ? 1 : 2));
     const size_t grid = total < slots ? total : slots;
     const unsigned* order = nullptr;
     const int order_stride = ((B + 7) / 8) * W;

@@ -627,7 +627,7 @@ static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A
     // 2 waves per SIMD (232 VGPRs, no spill); the 3-per-SIMD build spills 244 B/lane and is 3-8 % behind at every batch
     // size (IGT_DEV_FLAGS = 32 selects it for A/B runs)
     const bool o3 = IGT_DEV_KERNELS && (P.dev & 32) != 0;
-    const size_t slots = (size_t)A.n_cu * 4 * (o3 ? 3 : 2);
+    const size_t slots = (size_t)A.n_cu * 4 * (o3 ? 3 : (A.waves_per_simd == 1 ? 1 : 2));
     const size_t grid = total < slots ? total : slots;
     const unsigned* order = nullptr;
     const int order_stride = ((B + 7) / 8) * W;

@@ -41,6 +41,7 @@ struct SolveArgs {   // all device pointers
     // float path: feasible candidates appended by the search pass (count, scenario, candidate in rec_viol's storage)
     unsigned* work_counter;         // search_fast_kernel's 8 unit counters, 256 B apart (zeroed before every launch)
     int n_cu;                       // compute units (sizes the persistent search grid)
+    int waves_per_simd;             // of the persistent search grid: 2, or 1 when solves overlap (igt_set_concurrency); 0 = 2
     double* ckpt;                   // [ck_parts-1][B*Wk] horizon checkpoints of the search pass for emit (null: none)
     int ck_parts;                   // pieces the horizon is emitted in (igt_device.h Seg / Ckpt)
     unsigned* queue_order;          // [8][ceil(B/8) W] longest-first unit order of the search queues (null: index order)

@@ -67,6 +67,7 @@ SYMBOLS = {
     'igt_comm_destroy': (_i, [_vp]),
     'igt_allgather_controls_f32': (_i, [_vp, _i32, _vp, _vp, _vp]),
     'igt_allgather_controls_f64': (_i, [_vp, _i32, _vp, _vp, _vp]),
+    'igt_set_concurrency': (_i, [_vp, _i32]),
     'igt_set_profiling': (_i, [_vp, _i]),
     'igt_get_kernel_ms': (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     'igt_algorithmic_bytes_per_solve': (_i, [_vp, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

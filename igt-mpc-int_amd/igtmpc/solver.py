@@ -103,6 +103,11 @@ class BatchSolver:
         self._check(self.lib.igt_set_value_net(self._h, len(layers), dims_a.ctypes.data, flat.ctypes.data,
                                            Wn_c.ctypes.data, mu_c.ctypes.data, float(sigma_t), float(mu_t)))
 
+    def set_concurrency(self, solves_in_flight):
+        """Solves the caller keeps in flight on the device at a time, on other handles / streams (igtmpc.h igt_set_concurrency):
+        from 3 on, the persistent search kernels take one wave per SIMD instead of two so that two of them run side by side."""
+        self._check(self.lib.igt_set_concurrency(self._h, int(solves_in_flight)))
+
     def set_profiling(self, on=True):
         self._check(self.lib.igt_set_profiling(self._h, int(on)))
 

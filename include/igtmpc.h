@@ -289,6 +289,17 @@ int igt_comm_destroy(igt_handle* h);
 int igt_allgather_controls_f32(igt_handle* h, int32_t B_local, const float* u_out, float* u0_all, void* stream);
 int igt_allgather_controls_f64(igt_handle* h, int32_t B_local, const double* u_out, double* u0_all, void* stream);
 
+/* How many solves the caller keeps in flight on this device at a time -- on other handles and streams -- including this
+ * handle's (default 1).  The search kernels are persistent: with 1 a kernel starts as many waves as the device holds, two per
+ * SIMD, which is fastest for a solve that has the device to itself.  When solves overlap, a second kernel only gets wave
+ * slots as the first one drains, and a slot that has been vacated stays idle for tens of microseconds before the next
+ * workgroup runs there; with `solves_in_flight` >= 3 a search kernel takes one wave per SIMD, so that two kernels are
+ * resident side by side and each one's waves run faster while the other's are being replaced (measured at B = 4096 with four
+ * solves in flight: 0.187 -> 0.176 ms per step; one solve alone: 0.277 -> 0.324, hence a setting and not the default; with
+ * two in flight the streams of this runtime end up on one hardware queue and run one after the other, so 2 is treated as 1).
+ * Results do not depend on it.  IGT_E_INVALID unless 1 <= solves_in_flight <= 64. */
+int igt_set_concurrency(igt_handle* h, int32_t solves_in_flight);
+
 /* Per-kernel timing with HIP events on the launch stream (used by bench.py for the
  * roofline line).  While enabled, every solve records events around its kernels;
  * igt_get_kernel_ms synchronises on them and returns the last call's durations. */

@@ -550,6 +550,14 @@ def test_production_kernel_switches_change_nothing(igt, dtype, cand, monkeypatch
             s.set_cinf(*_cinf())
             outs[flag] = s.solve(*_args(b))
     monkeypatch.delenv('IGT_DEV_FLAGS')
+    # igt_set_concurrency: the search kernels take one wave per SIMD when the caller overlaps solves -- same answers
+    with igt.BatchSolver(dtype=dtype, cand_mode=cand) as s:
+        s.set_cinf(*_cinf())
+        s.set_concurrency(4)
+        outs['concurrency 4'] = s.solve(*_args(b))
+        for bad in (0, -3, 65):
+            with pytest.raises(igt.IgtError):
+                s.set_concurrency(bad)
     assert (outs[0]['status'] == 0).mean() > 0.5
     for flag, o in outs.items():
         for k in ('x', 'u', 'cost', 'argmin', 'status'):
