@@ -213,7 +213,11 @@ __global__ __launch_bounds__(QB_THREADS) void build_queues_kernel(KP P, int B, i
                 const float b0 = (float)kparams[(size_t)b * 3 + 0], b1 = (float)kparams[(size_t)b * 3 + 1], kv = (float)kparams[(size_t)b * 3 + 2];
                 const float reach = s0 + 1.5f * fmaxf(v0, 1.0f) * (float)(P.N * P.dt);
                 const bool arc = kv != 0.0f && reach >= b0 && s0 <= b1;
-                const float frac = p == 0 ? 0.95f : fminf(fmaxf(1.05f - 0.15f * v0, 0.4f), 0.95f);   // share of the horizon rolled
+                // share of the horizon rolled: the central slice lives to the end; the outer ones leave the lane the sooner the
+                // faster the vehicle is -- except where the route bends within reach: there the outer steering columns are the
+                // ones that can follow it, and every slice may live long; and the tracking family's units (acceleration rows,
+                // steering by feedback) all do (91 % of their wave-steps are executed)
+                const float frac = (p == 0 || arc || P.cand_mode == CAND_TRACK) ? 0.95f : fminf(fmaxf(1.05f - 0.15f * v0, 0.4f), 0.95f);
                 const float cost = frac * (arc ? 1.9f : 1.0f);                                        // 0.4 .. 1.8
                 c = (int)((1.85f - cost) * ((float)QC / 1.5f));
                 c = c < 0 ? 0 : (c > QC - 1 ? QC - 1 : c);
