@@ -30,6 +30,7 @@ The driver launches that as `python -m torch.distributed.run --nproc-per-node N 
 touches a GPU -- and fails loudly if it cannot.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import gc
 import hashlib
 import json
 import os
@@ -196,15 +197,27 @@ def rehearse_cpu(args, world, rank):
     dist.all_gather(got, tok)
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # the exchange's self-check (igtmpc.sharding.verify_gathered) on stand-in shards: every rank's "first-step controls" are a
+    # function of its rank, NaN rows (infeasible scenarios) included; a corrupted copy must be refused on every rank
+    from igtmpc.sharding import allgather_controls, verify_gathered
+    Bl = 24
+    u0 = torch.arange(Bl * 2, dtype=torch.float64).reshape(Bl, 2) * 0.37 + 1000.0 * rank
+    u0[3::5] = float('nan')
+    g = allgather_controls(u0, B_total=Bl * world)
+    chk = verify_gathered(u0, g)
+    bad = g.clone()
+    bad[(Bl * (world - 1) + 1) % (Bl * world), 1] += 1e-9          # one bit of another rank's block
+    chk_bad = verify_gathered(u0, bad) if world > 1 else dict(ok=False)
     if rank == 0:
         B = args.batch if args.batch else default_batch(world, args.gt)
         fake = lambda Bm: dict(dtype=args.dtype, B=Bm, elapsed=float(t.item()), steps=args.steps, value=None, ms_per_step=None,
                                search_ms=None, emit_ms=None, rd=0, wr=0, feasible=None, in_flight=args.in_flight,
-                               lane_search_ms=None, lane_emit_ms=None)
+                               lane_search_ms=None, lane_emit_ms=None, overlap_checked=None,
+                               exchange=dict(chk, lanes=args.in_flight) if world > 1 else None)
         same = fake(default_batch(1)) if (world > 1 and B != default_batch(1) and not args.batch and not args.gt) else None
         line = assemble_line(args, fake(B), n_gpus=world, world=world, backend=dist.get_backend(), exchange=world > 1,
                              same_work=same, n_layers=3 if args.gt else 0)
-        line.update({'rehearsal': True, 'ranks_seen': dist.get_world_size(), 'backend': dist.get_backend(),
+        line.update({'rehearsal': True, 'backend': dist.get_backend(), 'corrupted_gather_refused': not chk_bad['ok'],
                      'tokens': [int(x.item()) for x in got], 'max_over_ranks_s': float(t.item()),
                      'spawned_by_bench': os.environ.get('IGT_BENCH_SPAWNED') == '1'})
         print(json.dumps(line), flush=True)
@@ -306,6 +319,14 @@ def assemble_line(args, head, n_gpus, world, backend, exchange, other=None, seri
                       'f32': 'igt_solve_batch_f32: <= 1e-5*max(1,|ref|) except trajectories whose curvature switch is '
                              'decided inside float32 noise (share measured in tests/test_gpu_parity.py)'},
     }
+    # self-checks of the timed regime (untimed, after it): lanes bit-equal to a solve alone; gathered vectors complete
+    line['overlap_checked'] = head.get('overlap_checked')
+    ex = head.get('exchange')
+    line['ranks_seen'] = ex['ranks_seen'] if ex else 1
+    if exchange:
+        line['exchange_checked'] = bool(ex and ex['ok'])
+        line['per_rank_B_local'] = ex['per_rank_B_local'] if ex else None
+        line['config']['ranks_seen'] = ex['ranks_seen'] if ex else world
     if F > 1:
         line['pipelined'] = {
             'solves_in_flight': F, 'ms_per_step': head['ms_per_step'],
@@ -414,6 +435,7 @@ def main():
     N, C = N_HORIZON, N_CAND
     B = args.batch if args.batch else default_batch(n_gpus, args.gt)
     batches = {}
+    checks_log = []          # one entry per measurement: the untimed self-checks of the regime it timed
 
     def measure(dtype, Bm, steps, warmup, in_flight=None, cand_mode='lattice', gt=None, settle_ms=None):
         """settle + W untimed + K timed steps of the `dtype` entry point at Bm scenarios per GPU, then per-kernel HIP
@@ -493,6 +515,13 @@ def main():
                 n_settle = int(ns.item())
             for _ in range(n_settle):
                 step()
+        # the self-check below reads every lane's outputs: a lane the overlapped steps never wrote would show this sentinel
+        torch.cuda.synchronize(dev)
+        for o in outs:
+            o['argmin'].fill_(-5)
+        if exchange:
+            for g in gathered:
+                g.fill_(-5.0)
         for _ in range(warmup):
             step()
         fence()
@@ -506,6 +535,28 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=f'cuda:{dev}')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+
+        # ---- untimed self-check of the regime just timed: every lane's outputs -- written by solves
+        # that overlapped the other lanes' -- must be, bit for bit, what ONE solve of the same batch gives with the device to
+        # itself; and every lane's gathered action vector must hold every rank's u*[:, :, 0] (checksums all-reduced from the
+        # shards, igtmpc.sharding.verify_gathered).  A line whose check fails is not printed (main()).
+        torch.cuda.synchronize(dev)
+        solvers[0].set_concurrency(1)
+        alone = solvers[0].solve(*dargs)                   # fresh output buffers, current stream, nothing else in flight
+        torch.cuda.synchronize(dev)
+        solvers[0].set_concurrency(F)
+        bits = lambda t: t.contiguous().view(torch.int64 if t.element_size() == 8 else torch.int32)
+        overlap_checked = all(bool(torch.equal(bits(o[k]), bits(alone[k]))) for o in outs for k in ('x', 'u', 'cost', 'argmin', 'status'))
+        exch = None
+        if exchange:
+            from igtmpc.sharding import verify_gathered
+            u0_alone = alone['u'][:, :, 0].contiguous()
+            res = [verify_gathered(u0_alone, g) for g in gathered]
+            exch = dict(ok=all(r['ok'] for r in res), ranks_seen=res[0]['ranks_seen'],
+                        per_rank_B_local=res[0]['per_rank_B_local'], lanes=F)
+        feasible = float((alone['status'] == 0).float().mean().item())
+        del alone
+        checks_log.append(dict(dtype=dtype, B=Bm, in_flight=F, cand=cand_mode, gt=gt, overlap_checked=overlap_checked, exchange=exch))
 
         # per-kernel durations: HIP events recorded by the library on the launch stream, same workload.
         # (1) pipelined runs: every lane profiles its own kernels while the other lanes' kernels overlap them
@@ -540,10 +591,16 @@ def main():
         res = dict(dtype=dtype, B=Bm, elapsed=elapsed, steps=steps, value=Bm * n_gpus * steps / elapsed,
                    ms_per_step=elapsed / steps * 1e3, search_ms=float(np.mean(ks)), emit_ms=float(np.mean(ke)),
                    lane_search_ms=lane_s, lane_emit_ms=lane_e, in_flight=F, settle_steps=n_settle, host_issue_ms=issued / steps * 1e3,
-                   rd=rd, wr=wr, feasible=float((out['status'] == 0).float().mean().item()), batch=batch)
+                   rd=rd, wr=wr, feasible=feasible, batch=batch, overlap_checked=overlap_checked, exchange=exch)
+        # ordered teardown ("exit-time abort"): nothing of this measurement is left to interpreter or
+        # static destructors -- device idle, exchange buffers and lane streams dropped, handles destroyed, cache released
+        torch.cuda.synchronize(dev)
+        if exchange:
+            del u0_buf, gathered
         for sv in solvers:
             sv.close()
-        del dargs, outs
+        del dargs, outs, out, solver, solvers, lanes
+        gc.collect()
         torch.cuda.empty_cache()
         return res
 
@@ -582,6 +639,25 @@ def main():
                             'kernels_ms': {'search_incl_value_net': m['search_ms'], 'emit': m['emit_ms']},
                             'feasible_fraction': m['feasible']})
 
+    # a `value` measured in a regime whose answers were not confirmed is not printed (every rank learns of any rank's failure:
+    # verify_gathered reduces its flag; the lane check is reduced here)
+    bad = [m for m in checks_log if m['overlap_checked'] is not True or (exchange and not (m['exchange'] and m['exchange']['ok']))]
+    n_bad = len(bad)
+    if exchange:
+        nb = torch.tensor([n_bad], dtype=torch.int64, device=f'cuda:{dev}')
+        dist.all_reduce(nb, op=dist.ReduceOp.MAX)
+        n_bad = int(nb.item())
+    if n_bad:
+        if rank == 0:
+            print('bench.py: the self-check of the timed regime FAILED (overlapped lanes differ from a solve alone, or a gathered '
+                  'action vector is incomplete) -- no line is printed: ' +
+                  '; '.join(f"{m['dtype']} {m['cand']} gt={m['gt']} B={m['B']} F={m['in_flight']} overlap_checked={m['overlap_checked']} "
+                            f"exchange={m['exchange']}" for m in bad),
+                  file=sys.stderr, flush=True)
+        if exchange:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(3)
     if rank == 0:
         n_layers = len(shipped_value_net(args.gt)['layers']) if args.gt else 0
         line = assemble_line(args, head, n_gpus, world, backend, exchange, other=other, serial=serial, tracking=tracking,
@@ -589,9 +665,15 @@ def main():
         line['config']['settle_steps'] = head['settle_steps']
         line['host_issue_ms_per_step'] = head.get('host_issue_ms')      # host time to enqueue one step; near ms_per_step: host-bound
         print(json.dumps(line), flush=True)
+    # ordered exit: measurements dropped, device idle, process group destroyed -- before the interpreter starts tearing down
+    del head, serial, tracking, same_work, other, batches
+    gc.collect()
+    torch.cuda.synchronize(dev)
     if exchange:
         dist.barrier()
+        torch.cuda.synchronize(dev)
         dist.destroy_process_group()
+    torch.cuda.empty_cache()
 
 
 if __name__ == '__main__':

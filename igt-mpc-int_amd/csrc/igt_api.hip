@@ -64,39 +64,65 @@ struct igt_handle {
     int32_t comm_B_local;  // shard size of the communicator's first all-gather (0 = none yet); later calls must match
     void* d_u0;            // [B_local,2] first-step controls staged for the all-gather
     size_t u0_bytes;
+    int dev_ckpt;          // IGT_DEV_CKPT / IGT_DEV_TRAJ_MAX (threshold sweeps), read once at igt_create; -1: not set
+    int dev_traj_max;
 };
 
 namespace {
 
 // RCCL is bound at run time (dlopen), not at link time: a single-GPU user needs no RCCL at all, and a process that
 // already carries one (torch ships its own librccl.so.1) must not get a second copy.
+// Lifetime: the binding is opened by the first user -- igt_comm_unique_id for the length of the call, igt_comm_init for as
+// long as its communicator lives -- and closed (dlclose) when the last communicator is destroyed (igt_comm_destroy /
+// igt_destroy).  Nothing is left to static destructors: `g_rccl` is plain data, and at process exit no handle of the
+// library refers to a DSO whose own teardown order it does not control ("exit-time abort").
 struct IgtNcclId { char internal[IGT_COMM_ID_BYTES]; };
 struct Rccl {
-    void* lib = nullptr;
-    int (*GetUniqueId)(IgtNcclId*) = nullptr;
-    int (*CommInitRank)(void**, int, IgtNcclId, int) = nullptr;
-    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
+    void* lib;
+    int users;
+    int (*GetUniqueId)(IgtNcclId*);
+    int (*CommInitRank)(void**, int, IgtNcclId, int);
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t);
+    int (*CommDestroy)(void*);
+    const char* (*GetErrorString)(int);
 };
-Rccl* rccl() {
-    static Rccl r;
-    static std::once_flag once;          // handles are per thread-group; two of them may reach igt_comm_* together
-    std::call_once(once, [] {
+Rccl g_rccl = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+std::mutex g_rccl_mu;          // handles are per thread-group; two of them may reach igt_comm_* together
+
+// one more user of the binding (opens it when there is none); null: RCCL cannot be loaded
+Rccl* rccl_acquire() {
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    Rccl& r = g_rccl;
+    if (!r.lib) {
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names)
             if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;          // one the process already mapped
         for (int i = 0; !r.lib && i < 3; ++i) r.lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
-        if (r.lib) {
-            r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
-            r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
-            r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
-            r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
-            r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
-            if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) r.lib = nullptr;
+        if (!r.lib) return nullptr;
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+        if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) {
+            dlclose(r.lib);
+            r.lib = nullptr;
+            return nullptr;
         }
-    });
-    return r.lib ? &r : nullptr;
+    }
+    ++r.users;
+    return &r;
+}
+// the binding of a live communicator (its handle holds a use: never null while h->comm is set)
+Rccl* rccl() { return g_rccl.lib ? &g_rccl : nullptr; }
+void rccl_release() {
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    Rccl& r = g_rccl;
+    if (r.users > 0 && --r.users == 0 && r.lib) {
+        dlclose(r.lib);          // drops this library's reference; a copy torch mapped stays mapped for torch
+        r.lib = nullptr;
+        r.GetUniqueId = nullptr; r.CommInitRank = nullptr; r.AllGather = nullptr; r.CommDestroy = nullptr; r.GetErrorString = nullptr;
+    }
 }
 int rccl_fail(Rccl* r, const char* what, int rc) {
     return fail(IGT_E_HIP, std::string(what) + ": " + (r && r->GetErrorString ? r->GetErrorString(rc) : "RCCL error"));
@@ -315,8 +341,8 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     int ck_parts = 1;
     if (sizeof(T) == 4 && B <= 2048 && p.N % 4 == 0 && p.N >= 8) ck_parts = 4;
     else if (sizeof(T) == 4 && B <= 2048 && p.N % 2 == 0 && p.N >= 4) ck_parts = 2;
-    if (const char* e = std::getenv("IGT_DEV_CKPT")) {
-        const int v = std::atoi(e);
+    if (h->dev_ckpt >= 0) {
+        const int v = h->dev_ckpt;
         if (sizeof(T) == 4 && v >= 1 && v <= igt::SEG_MAX_PARTS && p.N % v == 0 && p.N >= 2 * v) ck_parts = v;
     }
     const bool use_ckpt = ck_parts > 1;
@@ -326,7 +352,7 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     // hidden behind a lone wave's dependent chains; with several units per SIMD they are not: a closed loop of 512
     // problems per step ran 0.32 ms per step with them against 0.30 without, 0.43 against 0.36 at 1024)
     size_t traj_max_units = (size_t)h->n_cu * 4;
-    if (const char* e = std::getenv("IGT_DEV_TRAJ_MAX")) traj_max_units = (size_t)std::min(std::max(std::atoi(e), 0), 8192) * Wk;   // sweeps: a batch size
+    if (h->dev_traj_max >= 0) traj_max_units = (size_t)std::min(h->dev_traj_max, 8192) * Wk;   // sweeps: a batch size
     const bool capture = sizeof(T) == 8 && !exact64 && (size_t)B * Wk <= traj_max_units && (p.C % 64) == 0;
     const size_t traj_doubles = capture ? (size_t)B * Wk * igt::traj_unit_doubles(p.N) : 0;
     double* d_cpar = nullptr;
@@ -725,6 +751,9 @@ int igt_create(const igt_params* p, int device, igt_handle** out) {
     while ((p->C / 64) % h->nc) h->nc /= 2;
     h->n_cu = 256;
     h->concurrency = 1;
+    h->dev_ckpt = -1; h->dev_traj_max = -1;      // developer sweeps: the environment is read here, not on every solve
+    if (const char* e = std::getenv("IGT_DEV_CKPT")) h->dev_ckpt = std::max(std::atoi(e), 0);
+    if (const char* e = std::getenv("IGT_DEV_TRAJ_MAX")) h->dev_traj_max = std::max(std::atoi(e), 0);
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) h->n_cu = v; }
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(IGT_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
@@ -748,7 +777,7 @@ int igt_destroy(igt_handle* h) {
     if (h->d_net) (void)hipFree(h->d_net);
     if (h->d_routes) (void)hipFree(h->d_routes);
     if (h->d_u0) (void)hipFree(h->d_u0);
-    if (h->comm) { if (Rccl* r = rccl()) (void)r->CommDestroy(h->comm); }
+    if (h->comm) { if (Rccl* r = rccl()) (void)r->CommDestroy(h->comm); h->comm = nullptr; rccl_release(); }
     for (int i = 0; i < 3; ++i) (void)hipEventDestroy(h->ev[i]);
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1019,10 +1048,13 @@ int igt_cartesian_euler_f64(igt_handle* h, int32_t n, int32_t T, const double* z
 
 int igt_comm_unique_id(void* id_out) {
     if (!id_out) return fail(IGT_E_INVALID, "null argument");
-    Rccl* r = rccl();
+    Rccl* r = rccl_acquire();
     if (!r) return fail(IGT_E_STATE, "RCCL (librccl.so.1) could not be loaded");
     IgtNcclId id;
-    if (int rc = r->GetUniqueId(&id)) return rccl_fail(r, "ncclGetUniqueId", rc);
+    const int rc = r->GetUniqueId(&id);
+    const int ret = rc ? rccl_fail(r, "ncclGetUniqueId", rc) : IGT_OK;
+    rccl_release();
+    if (ret) return ret;
     std::memcpy(id_out, id.internal, IGT_COMM_ID_BYTES);
     return IGT_OK;
 }
@@ -1031,13 +1063,13 @@ int igt_comm_init(igt_handle* h, int32_t world, int32_t rank, const void* id) {
     if (!h || !id) return fail(IGT_E_INVALID, "null argument");
     if (world < 1 || rank < 0 || rank >= world) return fail(IGT_E_INVALID, "need 0 <= rank < world");
     if (h->comm) return fail(IGT_E_STATE, "communicator already initialised (igt_comm_destroy first)");
-    Rccl* r = rccl();
+    Rccl* r = rccl_acquire();          // held until igt_comm_destroy / igt_destroy
     if (!r) return fail(IGT_E_STATE, "RCCL (librccl.so.1) could not be loaded");
-    HIPCHK(hipSetDevice(h->device));
+    if (hipError_t e = hipSetDevice(h->device)) { rccl_release(); return fail(IGT_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
     IgtNcclId nid;
     std::memcpy(nid.internal, id, IGT_COMM_ID_BYTES);
     void* comm = nullptr;
-    if (int rc = r->CommInitRank(&comm, world, nid, rank)) return rccl_fail(r, "ncclCommInitRank", rc);
+    if (int rc = r->CommInitRank(&comm, world, nid, rank)) { const int ret = rccl_fail(r, "ncclCommInitRank", rc); rccl_release(); return ret; }
     h->comm = comm; h->comm_world = world; h->comm_rank = rank; h->comm_B_local = 0;
     return IGT_OK;
 }
@@ -1047,9 +1079,12 @@ int igt_comm_destroy(igt_handle* h) {
     if (!h->comm) return IGT_OK;
     Rccl* r = rccl();
     HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));          // no all-gather of this handle is still in flight on its own stream
     const int rc = r ? r->CommDestroy(h->comm) : 0;
     h->comm = nullptr; h->comm_world = 1; h->comm_rank = 0; h->comm_B_local = 0;
-    return rc ? rccl_fail(r, "ncclCommDestroy", rc) : IGT_OK;
+    const int ret = rc ? rccl_fail(r, "ncclCommDestroy", rc) : IGT_OK;
+    rccl_release();                                   // the last communicator closes the binding
+    return ret;
 }
 
 

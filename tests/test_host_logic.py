@@ -190,6 +190,9 @@ def test_bench_gpus_2_without_torchrun_variables_spawns_two_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert line['ranks_seen'] == 2 and line['tokens'] == [0, 1] and line['spawned_by_bench'] is True
+    # the exchange's self-check ran over gloo: complete vector accepted on every rank, a one-bit corruption of another
+    # rank's block refused
+    assert line['exchange_checked'] is True and line['per_rank_B_local'] == [24, 24] and line['corrupted_gather_refused'] is True
 
 
 def test_bench_multi_gpu_gt_line_is_assembled_without_a_gpu():
@@ -222,6 +225,12 @@ def test_bench_multi_gpu_gt_line_is_assembled_without_a_gpu():
         assert abs(line['roofline']['achieved'] - (452 + 12) * B / 3.6e-3 / 1e9) < 1e-9
         assert 'one solve in flight' in line['roofline']['regime'] and line['pipelined']['solves_in_flight'] == 4
         assert line['valu_roofline']['bound'] == 'valu_busy'
+        # placeholders carry no checks: the keys are there and say so (main() refuses to print such a line on a GPU)
+        assert line['overlap_checked'] is None and line['exchange_checked'] is False
+        ok = dict(m(B), overlap_checked=True, exchange=dict(ok=True, ranks_seen=8, per_rank_B_local=[B] * 8, lanes=4))
+        line = bm.assemble_line(args, ok, n_gpus=8, world=8, backend='nccl', exchange=True, serial=m(B, 1), n_layers=3 if gt else 0)
+        assert line['overlap_checked'] is True and line['exchange_checked'] is True and line['ranks_seen'] == 8
+        assert line['per_rank_B_local'] == [B] * 8
         json.dumps(line)
 
 

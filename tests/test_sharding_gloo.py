@@ -36,7 +36,18 @@ def _worker(rank, world, port, B_total, ragged, q):
                           full['obs_xy'][lo:hi], None, None, P, C=64)
         u0 = first_controls(torch.from_numpy(np.nan_to_num(r['u'], nan=-9.0)))
         g = allgather_controls(u0, B_total=None if ragged else B_total)
-        q.put((rank, g.numpy()))
+        # the exchange's self-check (bench.py runs it untimed after the timed region): accepts the gathered vector, refuses
+        # one with a flipped bit in the OTHER rank's block, one with two rows swapped, and a truncated one -- on every rank
+        from igtmpc.sharding import verify_gathered
+        good = verify_gathered(u0, g)
+        olo, ohi = shard_range(B_total, 1 - rank, world)
+        flipped = g.clone()
+        flipped[olo, 0] = torch.nextafter(flipped[olo, 0], torch.tensor(1e9, dtype=flipped.dtype))
+        swapped = g.clone()
+        swapped[[olo, ohi - 1]] = swapped[[ohi - 1, olo]]
+        verdicts = (good['ok'], verify_gathered(u0, flipped)['ok'], verify_gathered(u0, swapped)['ok'],
+                    verify_gathered(u0, g[:-1])['ok'], good['ranks_seen'], good['per_rank_B_local'])
+        q.put((rank, (g.numpy(), verdicts)))
     finally:
         dist.destroy_process_group()
 
@@ -59,4 +70,7 @@ def test_two_rank_allgather_equals_unsharded(B_total, ragged):
     ref = O.solve_batch(full['x0'], full['u_prev'], full['kparams'], full['flags'], full['obs_xy'], None, None,
                         O.Params(), C=64)
     want = np.nan_to_num(ref['u'], nan=-9.0)[:, :, 0]
-    assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
+    assert np.array_equal(got[0][0], want) and np.array_equal(got[1][0], want)
+    sizes = [B_total - B_total // 2, B_total // 2]
+    for r in range(2):
+        assert got[r][1] == (True, False, False, False, 2, sizes), got[r][1]
