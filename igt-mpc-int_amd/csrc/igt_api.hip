@@ -358,11 +358,11 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     double* d_cpar = nullptr;
     {
         const size_t n_rec = value ? (size_t)B * p.C : 0;
-        const size_t need = traj_doubles * 8 + 256 + (size_t)B * 8 + 256 + (size_t)B * W * 12 + (size_t)B * 56 + 8192 + ckpt_bytes + (size_t)(B + 8) * Wk * 36 + 256 + n_rec * (2 * sizeof(T) + 16) +
+        const size_t need = traj_doubles * 8 + 256 + (size_t)B * 16 + 256 + (size_t)B * W * 12 + (size_t)B * 56 + 8192 + ckpt_bytes + (size_t)(B + 8) * Wk * 36 + 256 + n_rec * (2 * sizeof(T) + 16) +
                             (value ? (size_t)B * igt::VN_H * sizeof(T) + (size_t)B * Wk * 8 + (size_t)B * 8 + n_rec * 4 + 512 : 0) + 20 * 256;
         if (int rc = ensure_work(h, need, st)) return rc;
         Arena wa{(char*)h->d_work, 0};
-        A.part_J = wa.take<double>((size_t)B * W + (sizeof(T) == 8 ? (size_t)B : 0));      // double path: + [B] live-row masks (igt_kernels_f64.hip)
+        A.part_J = wa.take<double>((size_t)B * W + (sizeof(T) == 8 ? (size_t)2 * B : 0));  // double path: + [B] live-row masks + [B] incumbents (igt_kernels_f64.hip)
         A.part_c = wa.take<int32_t>((size_t)B * W);
         d_cpar = wa.take<double>((size_t)B * 4);
         const bool trace = (h->kp.dev & 256) != 0;      // developer trace: 32 B per unit behind the counters

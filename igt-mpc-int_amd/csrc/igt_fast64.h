@@ -336,14 +336,50 @@ __device__ __forceinline__ void fill_steer_table(const KP& P, const Scenario<dou
     __syncthreads();
 }
 
+// ---- the incumbent bound (search, progress cost; used by the tracking family, whose candidates hardly ever fail a verdict) ----
+// A candidate's cost is  J = (non-negative stage terms, mpc.py:361-364) - (s_N - s_0)  (mpc.py:372), and the progress still to
+// come after step k is bounded by the speed profile of the candidate's own acceleration row, which depends on nothing else:
+// every RK4 stage derivative is  ds = v cos(.) / (1 - K ey) <= |v| / (1 - |K| |ey|),  the stage speeds of a control step lie
+// between v_k and v_k+1, so  s_k+1 - s_k <= lam dt max(|v_k|, |v_k+1|)  with lam = 1 when the scenario cannot meet its arc within
+// the horizon (K == 0 at every stage argument) and 1 / (1 - |kv| ey_b) else, ey_b bounding |ey| at any stage of a candidate that
+// is feasible at every node (|ey_k| <= ey_lim + tol, mpc.py:296-299; it moves by at most |v| per unit time in between).  Hence
+//     LB_k = J_k - (s_k - s_0) - rem_k,   rem_k = lam dt sum_{k' >= k} max(|v_k'|, |v_k'+1|)
+// is a lower bound of the final cost of a candidate that ends up feasible, and one with LB_k > J_inc -- the final cost of a
+// FEASIBLE candidate of the same scenario and the same pass, left by a unit that has finished (igt_kernels_f64.hip:
+// search_unit64 publishes with an atomic min, units run highest acceleration rows first) -- cannot win and cannot tie: it is
+// marked lost.  The winner is never among them, so cost / arg-min / trajectory are what they were, bit for bit; only HOW MANY
+// steps a unit rolls depends on which incumbents it saw (tools/bound_prune_probe.py: 0.84 -> 0.46 of the wave-steps).
+constexpr unsigned VIOL_PRUNED = 128u;            // internal to the search pass: never reported
+__device__ __forceinline__ unsigned long long cost_key(double J) {           // order-preserving map double -> u64
+    const unsigned long long b = (unsigned long long)__double_as_longlong(J);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double cost_of_key(unsigned long long k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
+// lam of the scenario, or 0: no usable bound (|kv| ey_b too close to 1)
+__device__ __forceinline__ double progress_slack(const KP& P, const Scenario<double>& S) {
+    const double vabs = fmax(fabs(P.v_min), fabs(P.v_max)) + P.tol + fmax(fabs(P.a_min), fabs(P.a_max)) * P.dt;
+    const double eyb = P.ey_lim + P.tol + 1.5 * P.dt * vabs;
+    const double q = fabs(S.kv) * eyb;
+    if (!(q < 0.5) || !(P.w_u >= 0.0)) return 0.0;                           // (a negative effort weight: stage terms of either sign)
+    const double lam = 1.0 / (1.0 - q);
+    const double reach = (P.N + 1) * P.dt * vabs * lam;                      // every stage argument stays within s_0 +- reach
+    const bool clear = S.kv == 0.0 || S.x0[2] + reach < S.b0 || S.x0[2] - reach >= S.b1;
+    return clear ? 1.0 : lam;
+}
+
 // XY = false (search only, decided per unit by obstacles_out_of_reach): x, y are neither integrated nor judged -- no candidate
 // that holds the speed box can come within d_min of any forecast position, and one that does not is infeasible already.
+// inc (search, CAND_TRACK, progress cost; may be null): the scenario's incumbent key, see above.
 template <int CAND, bool HI_ORDER, bool BOOK, bool UNIFORM, class Sink, bool EARLY_EXIT = false, bool STAB = false, int NRK = 0,
           bool XY = true>
 __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>& S, int cidx,
                                             const double* __restrict__ table, const double* __restrict__ cinf,
                                             Sink& sink, double& Jout, unsigned& vout, double& sN, double& vN,
-                                            const double* __restrict__ stab = nullptr, int stab_stride = 0) {
+                                            const double* __restrict__ stab = nullptr, int stab_stride = 0,
+                                            const unsigned long long* inc = nullptr) {
+    constexpr bool BOUND = CAND == CAND_TRACK && BOOK && UNIFORM && EARLY_EXIT;
     constexpr bool KEEP_PSI = Sink::kKeepsStates;
     // search only needs feasible-or-not: |ey|, box v and collision are folded into one running maximum, compared with
     // the tolerance when it is read (x > tol for some x  <=>  max x > tol; a NaN operand is ignored by both forms)
@@ -382,6 +418,27 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
     double cb_prev = 1.0, sb_prev = 0.0;
     double trk_sb = 0.0, trk_cb = 1.0;
     bool trk_followed = false;
+    // incumbent bound: rem = bound of the progress still to come (the row's own (a, v) recurrence rolled ahead, the statements of
+    // the loop below), jcut = incumbent + a margin far above the rounding of LB_k (1e-9: the comparison is mathematically strict)
+    double rem = 0.0, jcut = (double)INFINITY, seg_scale = 0.0;
+    if (BOUND && inc) {
+        seg_scale = progress_slack(P, S) * P.dt;
+        if (seg_scale > 0.0) {
+            double a2 = S.a_prev, v2 = S.x0[5];
+            for (int k = 0; k < P.N; ++k) {
+                double ba, bdf;
+                ramp_base<double>(S.ws, P.N, k, S.a_prev, S.df_prev, ba, bdf);
+                const double ta = track_accel_target(P, k, ba, da);
+                a2 = clampd(a2 + clampd(ta - a2, -P.rate_a, P.rate_a), P.a_min, P.a_max);
+                const double vn = fma(fp.dt, a2, v2);
+                rem += fmax(fabs(v2), fabs(vn));
+                v2 = vn;
+            }
+            rem *= seg_scale * (1.0 + 1e-12);
+        } else {
+            inc = nullptr;
+        }
+    }
 
     for (int k = 0; k < P.N; ++k) {
         // ---- controls of step k
@@ -447,6 +504,15 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
         // unused on straight routes; with one scenario per lane the votes of substeps() read them on every lane
         // (a straight route's break-points are +inf: d = -inf, "clear")
         if (!UNIFORM || fp.kv != 0.0) { w.d0 = s - fp.b0; w.d1 = s - fp.b1; }
+        if (BOUND && inc) {
+            // the incumbent is re-read every fourth step (a unit that started before its scenario's first unit finished picks it
+            // up on the way); agent scope: the units of a scenario may run on different XCDs, whose L2s are not coherent
+            if ((k & 3) == 0) {
+                const double ji = cost_of_key(__hip_atomic_load(inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                jcut = ji + 1e-9 * (1.0 + fabs(ji));
+            }
+            if ((J - (s - S.x0[2])) - rem > jcut) viol |= VIOL_PRUNED;
+        }
         if (BOOK && UNIFORM && EARLY_EXIT) {
             // search only: once every candidate of the slice has failed a verdict, nothing rolled further can win
             const bool lost = (viol != 0) | (LEAN && gmax > P.tol);
@@ -480,6 +546,7 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
         s += w.acc_s; ey += w.acc_ey; ep += w.acc_ep;
         if (XY) { x += w.acc_x; y += w.acc_y; }
         if (KEEP_PSI) psi += w.acc_psi;        // psi feeds nothing back (search: dead code)
+        if (BOUND && inc) rem -= seg_scale * fmax(fabs(v), fabs(fma(fp.dt, a, v)));      // this step's share of the bound is spent
         v = fma(fp.dt, a, v);
         const double nxt[7] = {x, y, s, ey, ep, v, psi};
         sink.state(0, k + 1, nxt);

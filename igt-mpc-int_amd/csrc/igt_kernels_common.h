@@ -156,9 +156,10 @@ __device__ __forceinline__ int unit_candidate(const KP& P, const UnitLayout& L, 
     if (L.kind == 0) return p * 64 + lane;
     const int lg = __ffs(P.G) - 1;                           // G is a power of two
     int rank, j, off = 0;
-    if (L.kind == 1) {                                       // lane = il * G + j
-        rank = p * L.per + (lane >> lg);
-        j = lane & (P.G - 1);
+    if (L.kind == 1) {                                       // lane = il * G + j; unit 0 holds the HIGHEST live rows (the ones that
+        rank = L.R - 1 - (p * L.per + (lane >> lg));         // make most progress -- where the winner usually is: its cost is the
+        j = lane & (P.G - 1);                                // incumbent the later units are pruned against, igt_fast64.h BOUND)
+        if (rank < 0) rank = L.R;
     } else {
         int r;
         if (L.kind == 3) {                                   // candidate number g = r R + q of the scenario's live ones
@@ -221,6 +222,10 @@ __global__ __launch_bounds__(QB_THREADS) void build_queues_kernel(KP P, int B, i
                 const float cost = frac * (arc ? 1.9f : 1.0f);                                        // 0.4 .. 1.8
                 c = (int)((1.85f - cost) * ((float)QC / 1.5f));
                 c = c < 0 ? 0 : (c > QC - 1 ? QC - 1 : c);
+                // float64 tracking units (row_mask given: cut along the acceleration axis, highest rows in unit 0): unit-rank-major
+                // -- every scenario's unit 0 before any unit 1 -- so that a later unit of a scenario starts when the earlier ones
+                // have left their best cost as its incumbent (igt_fast64.h BOUND)
+                if (P.cand_mode == CAND_TRACK && row_mask && !(P.dev & 262144)) c = W <= QC ? p : (p * QC) / W;
             }
         }
         cls[t] = c; rank[t] = 0;
@@ -259,9 +264,12 @@ __global__ __launch_bounds__(QB_THREADS) void build_queues_kernel(KP P, int B, i
 // owns one scenario of every block of 8 (queue_scenario) and deals them out scenario-major, or longest first when
 // the batch is small (build_queues_kernel); a wave whose queue is dry takes from the other queues in turn.
 // `unit(b, p)` rolls slice p of scenario b (float path: search_unit, 128 candidates; double path: search_unit64, 64).
+// p_major (no order table): item k of a queue is unit rank k / n_scen of scenario ordinal k mod n_scen -- every scenario's
+// unit 0 before any unit 1 (the float64 tracking family's incumbents) -- instead of scenario-major.
 template <class Unit>
 __device__ __forceinline__ void search_waves(const KP& P, int B, int W, int queues, unsigned* __restrict__ work_counter,
-                                             const unsigned* __restrict__ order, int order_stride, const Unit& unit) {
+                                             const unsigned* __restrict__ order, int order_stride, const Unit& unit,
+                                             bool p_major = false) {
     const unsigned q = blockIdx.x % (unsigned)queues, uW = (unsigned)W;
     const unsigned n_scen = ((unsigned)B + 7u) / 8u;          // blocks of 8 scenarios; queue q takes one of each
     const unsigned K = n_scen * uW;
@@ -294,7 +302,10 @@ __device__ __forceinline__ void search_waves(const KP& P, int B, int W, int queu
                 nxt = atomicAdd(counter, 1u);
                 nxt_item = (ord && nxt < K) ? ord[nxt] : 0u;
             }
-            const unsigned j = ord ? item >> 8 : k / uW, p = ord ? item & 255u : k - (k / uW) * uW;
+            unsigned j, p;
+            if (ord) { j = item >> 8; p = item & 255u; }
+            else if (p_major) { p = k / n_scen; j = k - p * n_scen; }
+            else { j = k / uW; p = k - j * uW; }
             const unsigned long long t0 = (P.dev & 256) ? wall_clock64() : 0ull;
             const int b = queue_scenario((int)qq, (int)j);
             if (b < B) unit(b, (int)p);

@@ -211,13 +211,27 @@ __global__ __launch_bounds__(256) void accel_rows_kernel(KP P, int B, const doub
         live = !(g > P.tol) && viol == 0;
     }
     const unsigned long long m = __ballot(live);
-    if (b < B && i == 0) row_mask[b] = (m >> (lane & ~(P.G - 1))) & (P.G >= 64 ? ~0ull : ((1ull << P.G) - 1ull));
+    if (b < B && i == 0) {
+        row_mask[b] = (m >> (lane & ~(P.G - 1))) & (P.G >= 64 ? ~0ull : ((1ull << P.G) - 1ull));
+        row_mask[B + b] = f64::cost_key((double)INFINITY);      // the scenario's incumbent of this pass: none yet (igt_fast64.h BOUND)
+    }
 }
 
 // launch-time bit of KP::dev (never taken from IGT_DEV_FLAGS): the masks of accel_rows_kernel sit behind the partials
 constexpr int DEV_LIVE_ROWS = 1 << 30;
+constexpr int DEV_NO_BOUND = 8388608;      // IGT_DEV_FLAGS: no incumbent bound in the tracking family's search (A/B runs, bitwise test)
 __device__ __forceinline__ const unsigned long long* live_rows_of(const KP& P, int B, int W, const double* part_J) {
     return (P.dev & DEV_LIVE_ROWS) ? reinterpret_cast<const unsigned long long*>(part_J + (size_t)B * W) : nullptr;
+}
+// the incumbents sit behind the masks: [B] keys, set to "none" by accel_rows_kernel
+template <int CAND, bool VALUE>
+__device__ __forceinline__ unsigned long long* incumbents_of(const KP& P, int B, int W, double* part_J) {
+    return (CAND == CAND_TRACK && !VALUE && (P.dev & DEV_LIVE_ROWS) && !(P.dev & (DEV_NO_BOUND | 262144)))
+               ? reinterpret_cast<unsigned long long*>(part_J + (size_t)B * W) + B : nullptr;
+}
+// queue items in unit-rank-major order when the tracking family's incumbents are in use and no order table was built
+__device__ __forceinline__ bool rank_major_items(const KP& P, int cand, bool value) {
+    return cand == CAND_TRACK && !value && (P.dev & DEV_LIVE_ROWS) && !(P.dev & (DEV_NO_BOUND | 262144));
 }
 
 #define IGT_SEARCH64_ARGS                                                                                            \
@@ -242,8 +256,9 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
                                               uint32_t* __restrict__ rec_viol, unsigned* __restrict__ rec_count,
                                               int32_t* __restrict__ rec_b, int2* __restrict__ unit_seg,
                                               const unsigned long long* __restrict__ row_mask = nullptr,
-                                              double* __restrict__ traj = nullptr) {
+                                              double* __restrict__ traj = nullptr, unsigned long long* inc_all = nullptr) {
     const int lane = threadIdx.x & 63;
+    unsigned long long* inc = inc_all ? inc_all + b : nullptr;
     const UnitLayout L = unit_layout(P, W, CAND, row_mask ? row_mask[b] : ~0ull);
     if (p >= L.n_units) {             // the scenario's live rows fit fewer units: this slice holds nothing
         if (lane == 0) {
@@ -291,9 +306,9 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
                                                                                     stab + col * 3, nj * 3);
         __syncthreads();                                  // the next unit of this wave rewrites the table
     } else if (far) {
-        f64::rollout_one<CAND, HI, true, true, NullSink, true, false, NRK, false>(P, S, c, table, cinf, sink, J, viol, sN, vN);
+        f64::rollout_one<CAND, HI, true, true, NullSink, true, false, NRK, false>(P, S, c, table, cinf, sink, J, viol, sN, vN, nullptr, 0, inc);
     } else {
-        f64::rollout_one<CAND, HI, true, true, NullSink, true, false, NRK, true>(P, S, c, table, cinf, sink, J, viol, sN, vN);
+        f64::rollout_one<CAND, HI, true, true, NullSink, true, false, NRK, true>(P, S, c, table, cinf, sink, J, viol, sN, vN, nullptr, 0, inc);
     }
     }
     if (VALUE) {   // terminal value network (mpc.py:369): append the feasible candidates for value_mfma_f64_kernel; the
@@ -322,7 +337,12 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
         const bool take = (oC >= 0) && (bestC < 0 || oJ < bestJ || (oJ == bestJ && oC < bestC));
         if (take) { bestJ = oJ; bestC = oC; }
     }
-    if (lane == 0) { part_J[b * W + p] = bestJ; part_c[b * W + p] = bestC; }
+    if (lane == 0) {
+        part_J[b * W + p] = bestJ; part_c[b * W + p] = bestC;
+        // the unit's best feasible cost is the scenario's incumbent from now on (device-scope atomic: the later units of the
+        // scenario may run on another XCD)
+        if (inc && bestC >= 0) atomicMin(inc, f64::cost_key(bestJ));
+    }
 }
 
 // persistent waves on the per-XCD queues (search_waves), 2 or 3 per SIMD like the float kernels.  NRK = 4: the build for the
@@ -331,15 +351,17 @@ template <int CAND, bool HI, bool VALUE, int NRK>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void search_f64_kernel_o2(IGT_SEARCH64_ARGS) {
     search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
         search_unit64<CAND, HI, VALUE, NRK>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN,
-                                       rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg, live_rows_of(P, B, W, part_J));
-    });
+                                       rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg, live_rows_of(P, B, W, part_J), nullptr,
+                                       incumbents_of<CAND, VALUE>(P, B, W, part_J));
+    }, rank_major_items(P, CAND, VALUE));
 }
 template <int CAND, bool HI, bool VALUE, int NRK>      // held to 256 registers for the tracking family (see search_fast_kernel_o2w)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void search_f64_kernel_o2w(IGT_SEARCH64_ARGS) {
     search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
         search_unit64<CAND, HI, VALUE, NRK>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN,
-                                       rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg, live_rows_of(P, B, W, part_J));
-    });
+                                       rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg, live_rows_of(P, B, W, part_J), nullptr,
+                                       incumbents_of<CAND, VALUE>(P, B, W, part_J));
+    }, rank_major_items(P, CAND, VALUE));
 }
 // small batches (captures_trajectories): the same search, every unit also leaves its 64 trajectories in `traj`
 template <int CAND, bool VALUE>
