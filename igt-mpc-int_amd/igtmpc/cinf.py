@@ -12,7 +12,7 @@ convex-polygon implementation of the same fixed point
 with X = {v<=5, a<=3, v>=-1, a>=-4}, U = {|da| <= dt*jerk}, A = [[1,dt],[0,1]], B = [0,1]^T.
 The result is returned as unit-normal half-planes  A_h [F,2] (v,a) <= b_h [F].
 PARITY UNPINNED against polytope (absent offline); tests pin it with invariance /
-maximality properties instead (tests/test_cinf.py)."""
+maximality properties instead (tests/test_properties.py / tests/test_host_logic.py)."""
 import numpy as np
 
 

@@ -389,12 +389,24 @@ def save_results(r, save_dir, eval_mode, sc, seed=2026, policy=None, timenow=Non
     E, M = x_cl.shape[0], x_cl.shape[1] // 7
     with open(out + '/mpc.yaml', 'w') as f:
         yaml.safe_dump(dict(policy or {}), f)
-    for name, arr in (('cl_traj.pkl', x_cl), ('u_cl.pkl', u_cl)):
-        path = out + '/' + name
-        if os.path.isfile(path):                                                               # evaluate.py:341-350: runs append
-            with open(path, 'rb') as f:
-                arr = np.concatenate([pickle.load(f), arr], axis=0)
-        with open(path, 'wb') as f:
+    # Runs append (evaluate.py:341-350).  The reference reads its own pickles back for that; this writer NEVER unpickles a
+    # file (a run directory may come from anywhere, and unpickling executes what the file says): what it has written so far is
+    # kept beside the pickles as plain arrays (.igt_run.npz, read with allow_pickle=False), the pickles are output only, and a
+    # directory that holds pickles but not that file -- one this package did not write -- is refused.
+    side = out + '/.igt_run.npz'
+    new = {'x_cl': x_cl, 'u_cl': u_cl, 'weights': np.ones((E, 2)), 'routes': np.array([list(p) for p in r['routes']]),
+           'deadlock': np.asarray(r['deadlock']).reshape(E, 1), 'initial_agents': x_cl[:, :, 0].reshape(E, M, 7)}
+    if os.path.isfile(side):
+        with np.load(side, allow_pickle=False) as old:
+            acc = {k: np.concatenate([old[k], new[k]], axis=0) for k in new}
+    elif any(os.path.isfile(out + '/' + n) for n in ('cl_traj.pkl', 'u_cl.pkl', 'evaluation_data.pkl')):
+        raise FileExistsError(f'{out} holds pickles this package did not write (no .igt_run.npz beside them): it does not '
+                              f'unpickle files to append to them; give another --save_dir')
+    else:
+        acc = new
+    np.savez(side, **acc)
+    for name, arr in (('cl_traj.pkl', acc['x_cl']), ('u_cl.pkl', acc['u_cl'])):
+        with open(out + '/' + name, 'wb') as f:
             pickle.dump(arr, f)
     step_s = np.asarray(r['solve_ms'], dtype=np.float64) / 1e3
     rows = []
@@ -410,16 +422,8 @@ def save_results(r, save_dir, eval_mode, sc, seed=2026, policy=None, timenow=Non
             w.writeheader()
         w.writerows(rows)
     if not gt:                                                                                 # evaluate.py:592-602
-        data = {'N': (policy or {}).get('N'), 'x_cl': x_cl, 'u_cl': u_cl, 'agent_types': ['CAV'] * M, 'weights': np.ones((E, 2)),
-                'routes': np.array([list(p) for p in r['routes']]), 'deadlock': np.asarray(r['deadlock']).reshape(E, 1),
-                'initial_agents': x_cl[:, :, 0].reshape(E, M, 7)}
-        path = out + '/evaluation_data.pkl'
-        if os.path.isfile(path):
-            with open(path, 'rb') as f:
-                old = pickle.load(f)
-            for k in ('x_cl', 'u_cl', 'weights', 'routes', 'deadlock', 'initial_agents'):
-                data[k] = np.concatenate([old[k], data[k]], axis=0)
-        with open(path, 'wb') as f:
+        data = dict({'N': (policy or {}).get('N'), 'agent_types': ['CAV'] * M}, **acc)
+        with open(out + '/evaluation_data.pkl', 'wb') as f:
             pickle.dump(data, f, protocol=pickle.HIGHEST_PROTOCOL)
     return run
 

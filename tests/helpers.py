@@ -58,3 +58,24 @@ def ambiguous_mask(ref, P, eps_margin=2e-5, eps_cost=2e-5, eps_bp=2e-5, bp=None,
     if bp is not None:
         amb |= (contender & (bp < eps_bp)).any(axis=1)
     return amb
+
+
+def verdict_margins(X, U, obs_xy, cinf_A, cinf_b, P):
+    """Worst signed violation PER VERDICT FAMILY (np_oracle.constraint_violation's bits 0, 1, 3, 4, 5; -inf where a family
+    does not apply): [..., 7].  Lets a test say that a differing verdict bit sits on its threshold."""
+    N = U.shape[-1]
+    shape = np.broadcast_shapes(X.shape[:-2], U.shape[:-2])
+    g = np.full(shape + (7,), -np.inf)
+    v = X[..., O.IV, :N]
+    g[..., 0] = np.max(np.maximum(P.v_min - v, v - P.v_max), axis=-1)
+    a, d = U[..., 0, :], U[..., 1, :]
+    g[..., 1] = np.max(np.maximum(np.maximum(P.a_min - a, a - P.a_max), np.maximum(-P.df_max - d, d - P.df_max)), axis=-1)
+    g[..., 3] = np.max(np.abs(X[..., O.IEY, :]) - P.ey_lim, axis=-1)
+    if cinf_A is not None and len(cinf_b):
+        t = cinf_A[:, 0] * X[..., O.IV, N - 1, None] + cinf_A[:, 1] * U[..., 0, N - 1, None] - cinf_b
+        g[..., 4] = np.max(t, axis=-1)
+    if obs_xy is not None and obs_xy.shape[-3] > 0:
+        dx = X[..., None, O.IX, 1:] - obs_xy[..., :, 0, 1:]
+        dy = X[..., None, O.IY, 1:] - obs_xy[..., :, 1, 1:]
+        g[..., 5] = np.max(P.d_min ** 2 - (dx * dx + dy * dy), axis=(-1, -2))
+    return g

@@ -15,6 +15,8 @@ from helpers import F32_EPS, F32_TIE, REL_TOL, ambiguous_mask, oracle_params, re
 
 
 def _draw(seed):
+    if seed >= 200:
+        return _draw_ext(seed)
     rng = np.random.default_rng([2026, seed])
     cfg = dict(
         N=int(rng.choice([4, 7, 12, 20, 33, 40])),
@@ -48,8 +50,41 @@ def _draw(seed):
     return cfg
 
 
+def _draw_ext(seed):
+    """The ranges include/igtmpc.h advertises beyond the reference's configuration: horizons up to IGT_MAX_N = 64 (with C = 256 the
+    slice's steering table fits LDS, with C = 64 it does not: both paths), up to IGT_MAX_OBS = 4 obstacles, batches either side
+    of the live-row units' bound."""
+    rng = np.random.default_rng([4026, seed])
+    cfg = dict(
+        N=int(rng.choice([48, 64, 64])),
+        n_rk4=int(rng.choice([2, 4, 4])),
+        dt=float(rng.choice([0.05, 0.1])),
+        C=int(rng.choice([64, 256, 256])),
+        cand=str(rng.choice(['lattice', 'ramp_hold', 'track'])),
+        n_obs=int(rng.choice([2, 3, 4, 4])),
+        B=int(rng.choice([5, 40, 130, 1100])),
+        terminal=bool(rng.random() < 0.6),
+    )
+    cfg['refine'] = int(rng.choice([0, 0, 1])) if cfg['cand'] != 'lattice' else 0
+    cfg['warm'] = bool(cfg['cand'] != 'lattice' and rng.random() < 0.4)
+    cfg['net'] = 0
+    if cfg['B'] * cfg['C'] * cfg['N'] * cfg['n_rk4'] * (1 + cfg['refine']) > 9e7:
+        cfg['B'] = 130 if cfg['C'] == 256 else 1100
+    lim = {}
+    if rng.random() < 0.5:
+        lim['v_max'] = float(rng.choice([4.0, 6.0]))
+    if rng.random() < 0.3:
+        lim['d_min'] = float(rng.choice([4.0, 7.0]))
+    if cfg['cand'] == 'track' and rng.random() < 0.5:
+        lim['track_env'] = float(rng.choice([0.0, 0.5]))
+    cfg['limits'] = lim
+    return cfg
+
+
 N_SEEDS = 40
 F32_SEEDS = range(100, 118)
+EXT_SEEDS = range(200, 214)
+EXT_F32_SEEDS = range(214, 220)
 
 
 @pytest.mark.gpu
@@ -63,6 +98,18 @@ def test_random_configuration_matches_oracle(seed, golden_dir):
 def test_random_configuration_matches_oracle_f32(seed, golden_dir):
     """The float32 entry points on the same kind of draws, at BASELINE.json's 1e-5 with the float32 set-asides of
     test_gpu_parity.py (threshold / break-point within 1e-7, near-ties; value network: 2e-5)."""
+    _run(seed, golden_dir, 'f32')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', EXT_SEEDS)
+def test_random_configuration_at_the_advertised_limits_matches_oracle(seed, golden_dir):
+    _run(seed, golden_dir, 'f64')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', EXT_F32_SEEDS)
+def test_random_configuration_at_the_advertised_limits_matches_oracle_f32(seed, golden_dir):
     _run(seed, golden_dir, 'f32')
 
 
@@ -81,11 +128,14 @@ def _run(seed, golden_dir, dtype):
     obs = b['obs_xy']                                                  # [B, 1, 2, N+1]
     if cfg['n_obs'] == 0:
         obs = np.zeros((B, 0, 2, N + 1), dtype=npdt)
-    elif cfg['n_obs'] == 2:                                            # a second vehicle, 9 m behind the first along its path
-        lag = obs.copy()
-        lag[:, 0, 0, :] -= 9.0 * np.cos(0.3 * np.arange(B))[:, None]
-        lag[:, 0, 1, :] -= 9.0 * np.sin(0.3 * np.arange(B))[:, None]
-        obs = np.ascontiguousarray(np.concatenate([obs, lag], axis=1))
+    elif cfg['n_obs'] >= 2:                                            # further vehicles, 9 m apart behind the first along its path
+        more = [obs]
+        for m in range(1, cfg['n_obs']):
+            lag = obs.copy()
+            lag[:, 0, 0, :] -= 9.0 * m * np.cos(0.3 * np.arange(B))[:, None]
+            lag[:, 0, 1, :] -= 9.0 * m * np.sin(0.3 * np.arange(B))[:, None]
+            more.append(lag)
+        obs = np.ascontiguousarray(np.concatenate(more, axis=1))
     rng = np.random.default_rng([7, seed])
     flags, u_prev, u_ws = b['flags'], b['u_prev'], None
     if cfg['warm']:       # previous solution = some lattice candidate of the scenario, shifted by one step (utils.py:354-363)
@@ -185,3 +235,8 @@ def test_the_draws_cover_the_template_space():
     assert any(c['refine'] > 0 for c in cfgs) and any(c['N'] > 20 for c in cfgs) and any(c['N'] < 12 for c in cfgs)
     assert any(c['n_rk4'] <= 2 and c['dt'] >= 0.1 for c in cfgs)          # the high-order offset polynomials
     assert any(c['B'] == 1 for c in cfgs) and any(c['B'] >= 17 for c in cfgs)
+    ext = [_draw(s) for s in list(EXT_SEEDS) + list(EXT_F32_SEEDS)]
+    assert {c['n_obs'] for c in ext} == {2, 3, 4} and {c['N'] for c in ext} == {48, 64} and {c['C'] for c in ext} == {64, 256}
+    assert any(c['N'] == 64 and c['C'] == 64 for c in ext) and any(c['N'] == 64 and c['C'] == 256 for c in ext)     # table fits / does not
+    assert any(c['B'] * c['C'] // 64 > 4096 for c in ext) and {c['cand'] for c in ext} == {'lattice', 'ramp_hold', 'track'}
+    assert any(c['n_obs'] == 4 and c['N'] == 64 for c in ext)

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 import np_oracle as O
-from helpers import F32_EPS, F32_TIE, REL_TOL, ambiguous_mask, oracle_params, oracle_solve, rel_err
+from helpers import F32_EPS, F32_TIE, REL_TOL, ambiguous_mask, oracle_params, oracle_solve, rel_err, verdict_margins
 
 pytestmark = pytest.mark.gpu
 
@@ -164,7 +164,7 @@ def test_f64_production_kernels_agree_with_oracle_order_kernels(igt, monkeypatch
         allr = s.rollout_all(*[a[:64] for a in _args(b)])
     assert np.array_equal(fast['status'], ref['status'])
     same = fast['argmin'] == ref['argmin']
-    assert same.mean() > 0.999
+    assert same.mean() > 0.999          # (and every difference is a tie of the two winners' costs to 1e-11: below)
     ok = same & (ref['status'] == 0)
     assert rel_err(fast['x'][ok], ref['x'][ok]).max() < 1e-11
     assert rel_err(fast['cost'][ok], ref['cost'][ok]).max() < 1e-11
@@ -177,6 +177,19 @@ def test_f64_production_kernels_agree_with_oracle_order_kernels(igt, monkeypatch
     assert np.array_equal(allf['U'], allr['U'])
     fin = np.isfinite(allr['cost'])
     assert rel_err(allf['cost'][fin], allr['cost'][fin]).max() < 1e-11
+    # a verdict bit may differ between the two arithmetics only where that verdict's worst margin sits on its threshold
+    # (within 1e-9 of feas_tol, by the oracle's numbers for the same candidates)
+    with igt.BatchSolver(dtype='f64') as s:
+        P = oracle_params(s)
+    A, bb = _cinf()
+    Uo = allr['U'].astype(np.float64)
+    X = O.rollout_frenet(O.apply_flags(b['x0'][:64], b['flags'][:64])[:, None, :], Uo, b['kparams'][:64, None, :], P)
+    gm = verdict_margins(X, Uo, b['obs_xy'][:64, None], A, bb, P)
+    diff_bits = allf['viol'] ^ allr['viol']
+    for bit in (0, 1, 3, 4, 5):
+        d = (diff_bits >> bit) & 1 == 1
+        assert (np.abs(gm[..., bit][d] - P.feas_tol) < 1e-9).all(), (bit, int(d.sum()))
+    assert (diff_bits & ~np.uint32(0b111011) == 0).all()
     assert (allf['viol'] == allr['viol']).mean() > 0.9995
 
 
@@ -257,12 +270,16 @@ def test_all_infeasible_reports_status_1(igt):
 
 
 @pytest.mark.parametrize('N,n_rk4,C,n_obs', [(10, 4, 256, 1), (40, 4, 64, 1), (20, 7, 64, 1), (20, 4, 1024, 1),
-                                             (20, 4, 256, 0), (20, 2, 256, 2)])
+                                             (20, 4, 256, 0), (20, 2, 256, 2), (64, 4, 256, 1), (64, 4, 64, 3), (64, 3, 1024, 1),
+                                             (20, 4, 256, 4), (20, 4, 256, 3)])
 def test_other_shapes_f64(igt, N, n_rk4, C, n_obs):
+    """... up to what include/igtmpc.h advertises: IGT_MAX_N = 64 (with the slice's steering table in LDS, C = 256 / 1024, and
+    without, C = 64) and IGT_MAX_OBS = 4 obstacles."""
     b = _batch(24, np.float64, N=N)
     obs = np.concatenate([b['obs_xy']] * max(n_obs, 1), axis=1)[:, :n_obs]
-    if n_obs == 2:
-        obs[:, 1] += 3.0
+    for m in range(1, n_obs):            # further vehicles: the first one's forecast, displaced
+        obs[:, m, 0] += 3.0 * m
+        obs[:, m, 1] -= 2.0 * (m - 1)
     with igt.BatchSolver(dtype='f64', N=N, n_rk4=n_rk4, C=C, n_obs=n_obs) as s:
         P = oracle_params(s)
         got = s.solve(b['x0'], b['u_prev'], b['kparams'], b['flags'], np.ascontiguousarray(obs))
@@ -481,14 +498,16 @@ def test_ramp_hold_with_refinement_matches_oracle(igt, dtype, tol, eps):
 
 
 @pytest.mark.parametrize('N,n_rk4,C,n_obs', [(10, 4, 256, 1), (40, 4, 64, 1), (20, 7, 64, 1), (20, 4, 1024, 1),
-                                             (20, 4, 256, 0), (20, 2, 256, 2), (20, 1, 256, 1)])
+                                             (20, 4, 256, 0), (20, 2, 256, 2), (20, 1, 256, 1), (64, 4, 256, 1), (64, 4, 64, 3),
+                                             (20, 4, 256, 4)])
 def test_other_shapes_f32(igt, N, n_rk4, C, n_obs):
     """float path at other discretisations (n_rk4 <= 2 switches to the longer offset polynomials), odd chunk
     counts (C = 64) and many slices (C = 1024)."""
     b = _batch(48, np.float32, N=N)
     obs = np.concatenate([b['obs_xy']] * max(n_obs, 1), axis=1)[:, :n_obs]
-    if n_obs == 2:
-        obs[:, 1] += 3.0
+    for m in range(1, n_obs):
+        obs[:, m, 0] += 3.0 * m
+        obs[:, m, 1] -= 2.0 * (m - 1)
     obs = np.ascontiguousarray(obs)
     with igt.BatchSolver(dtype='f32', N=N, n_rk4=n_rk4, C=C, n_obs=n_obs) as s:
         P = oracle_params(s)
@@ -568,7 +587,8 @@ def test_production_kernel_switches_change_nothing(igt, dtype, cand, monkeypatch
                                         ('lattice', 20, 256, 8200), ('track', 40, 256, 1500), ('lattice', 40, 256, 1500),
                                         ('lattice', 20, 1024, 700), ('track', 12, 1024, 700), ('ramp_hold', 20, 64, 4500),
                                         ('lattice', 12, 4096, 200), ('track', 8, 4096, 120), ('track', 20, 256, 16500),
-                                        ('track', 20, 64, 9000)])
+                                        ('track', 20, 64, 9000), ('lattice', 64, 256, 1100), ('lattice', 64, 64, 4200),
+                                        ('ramp_hold', 64, 256, 1100), ('track', 64, 256, 1100)])
 def test_units_of_live_acceleration_rows_change_nothing(igt, golden_dir, cand, N, C, B, monkeypatch):
     """The f64 search first rolls the G acceleration recurrences of every scenario (accel_rows_kernel) and builds its units from
     the rows that hold the speed box and the terminal set -- a failing row is infeasible in all of its columns, so it cannot
@@ -671,7 +691,7 @@ def test_cartesian_row_skip_changes_nothing(igt, dtype, cand, monkeypatch):
     """Search units whose obstacles are out of every speed-feasible candidate's reach roll without x, y (igt_device.h
     obstacles_out_of_reach; 70 % of the benchmark batch).  The switched-off build path (IGT_DEV_FLAGS = 65536) must give the
     same solve bit for bit -- on the benchmark batch, on a batch whose obstacle sits just inside / just outside the reach
-    bound, and with two obstacles of which one is near."""
+    bound, with two obstacles of which one is near, and with three and four (IGT_MAX_OBS)."""
     npdt = np.float64 if dtype == 'f64' else np.float32
     b = _batch(1024, npdt)
     far = (np.hypot(b['obs_xy'][:, 0, 0, 1:] - b['x0'][:, None, 0], b['obs_xy'][:, 0, 1, 1:] - b['x0'][:, None, 1]).min(axis=1) > 17.5)
@@ -684,7 +704,13 @@ def test_cartesian_row_skip_changes_nothing(igt, dtype, cand, monkeypatch):
     edge['obs_xy'][:, 0, 1, :] = (b['x0'][:, 1] + r * np.sin(ang))[:, None]
     two = {k: v[:256].copy() for k, v in b.items()}
     two['obs_xy'] = np.concatenate([b['obs_xy'][:256], np.full_like(b['obs_xy'][:256], -20.0)], axis=1)
-    for batch, n_obs in ((b, 1), (edge, 1), (two, 2)):
+    # three and four obstacles (IGT_MAX_OBS): far ones around a near or a far first one, the last one parked at the reach bound
+    many = {}
+    for n in (3, 4):
+        many[n] = {k: v[:256].copy() for k, v in b.items()}
+        extra = [np.full_like(b['obs_xy'][:256], 40.0 + 5.0 * m) for m in range(n - 2)] + [edge['obs_xy'][:256]]
+        many[n]['obs_xy'] = np.ascontiguousarray(np.concatenate([b['obs_xy'][:256]] + extra, axis=1))
+    for batch, n_obs in ((b, 1), (edge, 1), (two, 2), (many[3], 3), (many[4], 4)):
         outs = []
         for flag in ('0', '65536'):
             monkeypatch.setenv('IGT_DEV_FLAGS', flag)

@@ -527,6 +527,13 @@ def test_save_results_leaves_the_reference_drivers_run_directory(tmp_path):
                 d = pickle.load(f)
             assert d['x_cl'].shape == cl.shape and d['routes'].shape == (2 * E, M) and d['deadlock'].shape == (2 * E, 1)
             assert d['N'] == 40 and d['agent_types'] == ['CAV', 'CAV'] and d['initial_agents'].shape == (2 * E, M, 7)
+    # a run directory with pickles this package did not write is refused, not unpickled
+    foreign = tmp_path / 'foreign' / 'mpc_sc3_seed2026_t' / 'mpc'
+    foreign.mkdir(parents=True)
+    (foreign / 'cl_traj.pkl').write_bytes(b'cos\nsystem\n(S\'echo unpickled > ' + str(tmp_path / 'pwned').encode() + b'\'\ntR.')
+    with pytest.raises(FileExistsError, match='does not'):
+        save_results(r, str(tmp_path / 'foreign') + '/', 'mpc', 3, timenow='t')
+    assert not (tmp_path / 'pwned').exists()
 
 
 def test_load_reference_configs_reads_the_reference_files_and_refuses_another_intersection(tmp_path):
