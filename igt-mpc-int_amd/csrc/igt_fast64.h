@@ -215,7 +215,8 @@ struct Fast64 {
 
     // n_rk4 sub-steps of one control step.  The K == 0 variant (or the K == kv one) is taken when it is provably
     // exact for every active lane of the wave: straight route, or every lane's stage arguments stay outside (inside)
-    // the arc [b0, b1] by the travel bound |ds| <= 2 |v| (1/(1 - K ey) < 2 for any state near the road).
+    // the arc [b0, b1] by the travel bound |ds| <= 2 |v| (1/(1 - K ey) < 2 while |K ey| < 1/2: part of the "inside" vote --
+    // found by the N = 64 fuzz draws of round 4: an infeasible candidate 6 m off the road travelled 3.5 |v| dt in a step).
     // UNIFORM = false (emit: the lanes of a wave belong to different scenarios): the same choice by votes over the lanes.
     // the n_rk4 sub-steps of one variant; the reference's discretisation (4) is unrolled: no loop-carried register copies
     template <int MODE, bool XY>
@@ -249,7 +250,9 @@ struct Fast64 {
         {   // the whole control step: |travel| <= 2 dt (|v| + dt |a|)   (a straight route's d0, d1 are -inf: clear)
             const double m = (2.0 * dt) * (fabs(w.v1) + dt * fabs(a));
             const bool clear = (w.d0 + m < 0.0) | (w.d1 - m > 0.0);
-            const bool inside = (w.d0 - m > 0.0) & (w.d1 + m < 0.0);
+            // inside the arc the travel is v / (1 - K ey) per unit time: the factor 2 of the bound holds while |K ey| < 1/2 at
+            // every stage (|ey| moves by at most m / 2 within the step) -- a candidate metres off the road votes "general"
+            const bool inside = (w.d0 - m > 0.0) & (w.d1 + m < 0.0) & (fabs(kv) * (fabs(w.ey) + 0.5 * m) < 0.5);
             if (__all(clear)) {
                 run<1, XY>(sc, w);
                 return;
@@ -267,7 +270,7 @@ struct Fast64 {
             // travel bound of this sub-step: |o| <= h |ds| <= 2 h (|v| + |h a|)
             const double m = (2.0 * h) * (fabs(w.v1) + 2.0 * fabs(ha));
             const bool clear = (w.d0 + m < 0.0) | (w.d1 - m > 0.0);
-            const bool inside = (w.d0 - m > 0.0) & (w.d1 + m < 0.0);
+            const bool inside = (w.d0 - m > 0.0) & (w.d1 + m < 0.0) & (fabs(kv) * (fabs(w.ey) + 0.5 * m) < 0.5);
             if (__all(clear)) substep<1, XY>(sc, w);
             else if (__all(inside)) substep<2, XY>(sc, w);
             else substep<0, XY>(sc, w);
