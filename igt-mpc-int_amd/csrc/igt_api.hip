@@ -164,7 +164,7 @@ igt::KP make_kp(const igt_params& p, int F) {
     k.G = p.cand_mode == IGT_CAND_TABLE ? 1 : isqrt_exact(p.C);
     k.refine_it = 0;
     k.df_small = p.df_max < 0.78 ? 1 : 0;
-    { const char* e = getenv("IGT_DEV_FLAGS"); k.dev = (e ? atoi(e) : 0) & 0x3FFFFFFF; }      // bit 30 is set by the launchers
+    { const char* e = getenv("IGT_DEV_FLAGS"); k.dev = (e ? atoi(e) : 0) & 0x1FFFFFFF; }      // bits 29 and 30 are set by the launchers
     k.dt = p.dt;
     k.h = p.dt / p.n_rk4;                      // frenet.py:93
     k.l_r = p.l_r;
@@ -358,11 +358,15 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
     double* d_cpar = nullptr;
     {
         const size_t n_rec = value ? (size_t)B * p.C : 0;
-        const size_t need = traj_doubles * 8 + 256 + (size_t)B * 16 + 256 + (size_t)B * W * 12 + (size_t)B * 56 + 8192 + ckpt_bytes + (size_t)(B + 8) * Wk * 36 + 256 + n_rec * (2 * sizeof(T) + 16) +
+        // double path, progress cost: the unit winners' horizon checkpoints for the emit in pieces (24 doubles per unit)
+        const bool ck_ok = sizeof(T) == 8 && !value && !exact64 && p.N >= 8;
+        const size_t ck_doubles = ck_ok ? (size_t)B * W * igt::CK_RECORD_DOUBLES : 0;
+        const size_t need = traj_doubles * 8 + 256 + (size_t)B * 16 + ck_doubles * 8 + 256 + (size_t)B * W * 12 + (size_t)B * 56 + 8192 + ckpt_bytes + (size_t)(B + 8) * Wk * 36 + 256 + n_rec * (2 * sizeof(T) + 16) +
                             (value ? (size_t)B * igt::VN_H * sizeof(T) + (size_t)B * Wk * 8 + (size_t)B * 8 + n_rec * 4 + 512 : 0) + 20 * 256;
         if (int rc = ensure_work(h, need, st)) return rc;
         Arena wa{(char*)h->d_work, 0};
-        A.part_J = wa.take<double>((size_t)B * W + (sizeof(T) == 8 ? (size_t)2 * B : 0));  // double path: + [B] live-row masks + [B] incumbents (igt_kernels_f64.hip)
+        A.part_J = wa.take<double>((size_t)B * W + (sizeof(T) == 8 ? (size_t)2 * B : 0) + ck_doubles);  // double path: + [B] live-row masks + [B] incumbents + checkpoint records (igt_kernels_f64.hip)
+        A.ck_ok = ck_ok;
         A.part_c = wa.take<int32_t>((size_t)B * W);
         d_cpar = wa.take<double>((size_t)B * 4);
         const bool trace = (h->kp.dev & 256) != 0;      // developer trace: 32 B per unit behind the counters

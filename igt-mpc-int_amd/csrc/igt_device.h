@@ -380,6 +380,7 @@ struct Ckpt {
 struct NullSink {
     static constexpr bool kKeepsStates = false;
     __device__ __forceinline__ void ctrl(int, int, double, double) {}
+    __device__ __forceinline__ void slip(int, int, double, double) {}      // (sin, cos)(beta_k) of step k (igt_fast64.h SegSink)
     __device__ __forceinline__ void state(int, int, const double (&)[7]) {}
 };
 

@@ -228,8 +228,9 @@ struct Fast64 {
         }
     }
 
-    template <bool UNIFORM, bool XY = true>
-    __device__ __forceinline__ void substeps(double a, double sblr, Work& w) const {
+    // the constants of one control step (and the first sub-step's (sin, cos)(h/2 w2) in w): the same statements for the
+    // search / emit / rollout-all roll-outs and for the Cartesian rows rolled on their own (cartesian_rows)
+    __device__ __forceinline__ StepConst step_const(double a, double sblr, Work& w) const {
         const double ha = hh * a;
         StepConst sc;
         sc.ha = ha; sc.sblr = sblr;
@@ -240,6 +241,13 @@ struct Fast64 {
         }
         sc.s2d = 2.0 * sc.sd * sc.cd; sc.c2d = fma(-2.0 * sc.sd, sc.sd, 1.0);
         ssc(hh * ((w.v1 + ha) * sblr), w.sh, w.ch);                  // h/2 w2 of the first sub-step
+        return sc;
+    }
+
+    template <bool UNIFORM, bool XY = true>
+    __device__ __forceinline__ void substeps(double a, double sblr, Work& w) const {
+        const double ha = hh * a;
+        const StepConst sc = step_const(a, sblr, w);
         // UNIFORM: kv is a scalar (one scenario per wave) and the straight-route test is hoisted; otherwise (emit: one
         // scenario per lane) the whole-step decisions are taken by votes over the active lanes -- the variants are
         // bit-identical where they apply
@@ -375,14 +383,30 @@ __device__ __forceinline__ double progress_slack(const KP& P, const Scenario<dou
 // XY = false (search only, decided per unit by obstacles_out_of_reach): x, y are neither integrated nor judged -- no candidate
 // that holds the speed box can come within d_min of any forecast position, and one that does not is infeasible already.
 // inc (search, CAND_TRACK, progress cost; may be null): the scenario's incumbent key, see above.
+// ---- horizon checkpoints (SEGMODE): the winner's trajectory in pieces ----
+// emit rolls the winner again (keeping 147 state values per candidate alive in the search would cost more), and one roll-out is
+// a serial chain: 51 us at N = 20, all of it exposed when solves do not overlap.  The search pass therefore leaves, at the three
+// steps k = i N / 4, what a roll-out needs to RESUME there exactly: (s, ey, epsi), the carried pair (sin, cos)(epsi + beta_k-1)
+// and -- tracking family, whose steering is a feedback on the rolled state -- (df_k-1, sin beta_k-1, cos beta_k-1); everything
+// else of the state at node k is a function of the candidate alone (a and v: the row's recurrence; df of the lattice / ramp-hold /
+// table families: the column's) and is replayed.  SEGMODE 1 (search): every lane writes its values to its LDS slots `ck`
+// (field-major, stride 64: igt_kernels_f64.hip search_unit64 copies the unit winner's to HBM).  SEGMODE 2 (emit_seg_f64_kernel):
+// rolls steps [seg_k0, seg_k1) from the record `ck` (stride 1) of the checkpoint at seg_k0 -- the same statements on the same
+// numbers, so the four pieces are the unsegmented roll-out bit for bit.  x, y, psi feed nothing back and are rolled on their own
+// from the controls (cartesian_rows below).
+constexpr int CK_FIELDS = 8, CK_PARTS = 4;                      // record: s ey epsi s1 c1 [df sb cb]; pieces of the horizon
+__host__ __device__ inline int ckpt_step(int N, int i) { return (i * N) / CK_PARTS; }      // first step of piece i
+
 template <int CAND, bool HI_ORDER, bool BOOK, bool UNIFORM, class Sink, bool EARLY_EXIT = false, bool STAB = false, int NRK = 0,
-          bool XY = true>
+          bool XY = true, int SEGMODE = 0>
 __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>& S, int cidx,
                                             const double* __restrict__ table, const double* __restrict__ cinf,
                                             Sink& sink, double& Jout, unsigned& vout, double& sN, double& vN,
                                             const double* __restrict__ stab = nullptr, int stab_stride = 0,
-                                            const unsigned long long* inc = nullptr) {
+                                            const unsigned long long* inc = nullptr, double* ck = nullptr, int seg_k0 = 0,
+                                            int seg_k1 = 0) {
     constexpr bool BOUND = CAND == CAND_TRACK && BOOK && UNIFORM && EARLY_EXIT;
+    constexpr int CKF = CAND == CAND_TRACK ? 8 : 5;            // fields this family writes
     constexpr bool KEEP_PSI = Sink::kKeepsStates;
     // search only needs feasible-or-not: |ey|, box v and collision are folded into one running maximum, compared with
     // the tolerance when it is read (x > tol for some x  <=>  max x > tol; a NaN operand is ignored by both forms)
@@ -409,7 +433,7 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
         da = S.cpar[0] + cand_m(i, P.G, P.refine_it == 0) * S.cpar[2];
         ddf = S.cpar[1] + cand_m(j, P.G, P.refine_it == 0) * S.cpar[3];
     }
-    sink.state(0, 0, S.x0);
+    if (SEGMODE != 2 || seg_k0 == 0) sink.state(0, 0, S.x0);
     typename FP::Work w;
     w.d0 = w.d1 = 0.0;
     if (XY) sincos_reduced(S.x0[6], w.s2, w.c2);       // carried as (sin,cos)(psi + beta_k); beta_{-1} = 0
@@ -417,10 +441,37 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
     // (sin,cos)(epsi + beta_k) is carried the same way: the sub-steps turn the pair by exactly the angle epsi advances by
     // (substep(): h w2 - corr per sub-step), so after control step k-1 it holds (sin,cos)(epsi_k + beta_{k-1}) and step k
     // turns it by beta_k - beta_{k-1} -- no sincos(epsi) per control step (39 of ~460 instructions on a straight route)
-    sincos_reduced(S.x0[4], w.s1, w.c1);
     double cb_prev = 1.0, sb_prev = 0.0;
     double trk_sb = 0.0, trk_cb = 1.0;
     bool trk_followed = false;
+    int k_first = 0, k_last = P.N;
+    if (SEGMODE == 2) { k_first = seg_k0; k_last = seg_k1; }
+    if (SEGMODE == 2 && seg_k0 > 0) {
+        // resume at node seg_k0: the controls' own recurrences are replayed (the statements of the loop below), the state that
+        // depends on the roll-out comes from the checkpoint
+        for (int k = 0; k < seg_k0; ++k) {
+            if (CAND == CAND_LATTICE) {
+                a = clampd(a + da, P.a_min, P.a_max);
+                df = steer_next<CAND>(P, S, k, ddf, df);
+            } else if (CAND == CAND_RAMP_HOLD || CAND == CAND_TRACK) {
+                double ba, bdf;
+                ramp_base<double>(S.ws, P.N, k, S.a_prev, S.df_prev, ba, bdf);
+                const double ta = CAND == CAND_TRACK ? track_accel_target(P, k, ba, da) : clampd(ba + da, P.a_min, P.a_max);
+                a = clampd(a + clampd(ta - a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
+                if (CAND == CAND_RAMP_HOLD) df = steer_next<CAND>(P, S, k, ddf, df);
+            } else {
+                a = table[((size_t)cidx * 2 + 0) * P.N + k];
+                df = table[((size_t)cidx * 2 + 1) * P.N + k];
+            }
+            v = fma(fp.dt, a, v);
+        }
+        s = ck[0]; ey = ck[1]; ep = ck[2]; w.s1 = ck[3]; w.c1 = ck[4];
+        if (CAND == CAND_TRACK) { df = ck[5]; sb_prev = ck[6]; cb_prev = ck[7]; }
+        else slip_trig<CAND>(P, fp.lr_ratio, df, sb_prev, cb_prev);      // of df_{k0-1}: what step k0-1 left in (sb_prev, cb_prev)
+    } else {
+        sincos_reduced(S.x0[4], w.s1, w.c1);
+    }
+    int ck_q = 1, ck_k = (SEGMODE == 1 && ck) ? ckpt_step(P.N, 1) : -1;  // next checkpoint and its step (search; none without slots)
     // incumbent bound: rem = bound of the progress still to come (the row's own (a, v) recurrence rolled ahead, the statements of
     // the loop below), jcut = incumbent + a margin far above the rounding of LB_k (1e-9: the comparison is mathematically strict)
     double rem = 0.0, jcut = (double)INFINITY, seg_scale = 0.0;
@@ -443,7 +494,14 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
         }
     }
 
-    for (int k = 0; k < P.N; ++k) {
+    for (int k = k_first; k < k_last; ++k) {
+        if (SEGMODE == 1 && k == ck_k) {          // node k: what a roll-out needs to resume here
+            double* c = ck + (size_t)(ck_q - 1) * CKF * 64;
+            c[0] = s; c[64] = ey; c[128] = ep; c[192] = w.s1; c[256] = w.c1;
+            if (CAND == CAND_TRACK) { c[320] = df; c[384] = sb_prev; c[448] = cb_prev; }
+            ++ck_q;
+            ck_k = ck_q < CK_PARTS ? ckpt_step(P.N, ck_q) : -1;
+        }
         // ---- controls of step k
         if (CAND == CAND_LATTICE) {
             a = clampd(a + da, P.a_min, P.a_max);
@@ -488,6 +546,7 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
         } else {
             slip_trig<CAND>(P, fp.lr_ratio, df, sb, cb);
         }
+        sink.slip(0, k, sb, cb);
         const double sblr = sb * fp.inv_lr;
         // ---- bookkeeping of state k (cost in the oracle's order: control effort, epsi^2, ey^2 -- mpc.py:361-364)
         if (BOOK) {
@@ -578,6 +637,87 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
         Jout = 0.0; vout = 0; sN = 0.0; vN = 0.0;
     }
 }
+
+// The Cartesian rows x, y, psi of a trajectory from its controls alone (emit_seg_f64_kernel): they feed nothing back
+// (frenet.py:84-90), and what they read -- the stage speeds, the psi offsets, (sin, cos)(psi + beta) carried by rotation --
+// depends on (a_k, sin beta_k, cos beta_k) only.  The statements are rollout_one's: the pair is turned and re-normalised as
+// there, the step's constants come from step_const, and the sub-steps are substep<1, true> itself (its Frenet part reads
+// nothing of the Cartesian one and is dead code here) -- so x, y, psi come out bit for bit as in the full roll-out, whatever
+// sub-step variant that took (the variants differ in the Frenet part only).
+// ctl(k, a, sb, cb): the controls of step k -- read back from where the Frenet pieces left them (tracking family: the steering is
+// theirs to decide) or generated on the spot (the families whose controls are a function of the candidate alone: StepControls);
+// X, Y, PSI: [N+1] outputs with element stride `xs` (node 0 is written by the caller).
+template <bool HI_ORDER, int NRK, class Ctl>
+__device__ __forceinline__ void cartesian_rows(const KP& P, double x, double y, double psi, double v, Ctl& ctl,
+                                               double* X, double* Y, double* PSI, int xs) {
+    typedef Fast64<HI_ORDER, NRK> FP;
+    FP fp;
+    fp.init(P, (double)INFINITY, (double)INFINITY, 0.0);
+    typename FP::Work w;
+    w.d0 = w.d1 = 0.0; w.s1 = 0.0; w.c1 = 1.0; w.ey = 0.0;
+    sincos_reduced(psi, w.s2, w.c2);
+    double cb_prev = 1.0, sb_prev = 0.0;
+    for (int k = 0; k < P.N; ++k) {
+        double a, sb, cb;
+        ctl(k, a, sb, cb);
+        const double sblr = sb * fp.inv_lr;
+        w.v1 = v;
+        {
+            const double sdb = fma(sb, cb_prev, -(cb * sb_prev));
+            const double cdb = fma(cb, cb_prev, sb * sb_prev);
+            rotate(w.s2, w.c2, sdb, cdb);
+            const double r2 = fma(fma(w.s2, w.s2, w.c2 * w.c2), -0.5, 1.5);
+            w.s2 *= r2; w.c2 *= r2;
+            cb_prev = cb; sb_prev = sb;
+        }
+        w.acc_s = 0.0; w.acc_ey = 0.0; w.acc_ep = 0.0; w.acc_x = 0.0; w.acc_y = 0.0; w.acc_psi = 0.0;
+        const typename FP::StepConst sc = fp.step_const(a, sblr, w);
+        fp.template run<1, true>(sc, w);
+        x += w.acc_x; y += w.acc_y; psi += w.acc_psi;
+        v = fma(fp.dt, a, v);
+        X[(size_t)(k + 1) * xs] = x; Y[(size_t)(k + 1) * xs] = y; PSI[(size_t)(k + 1) * xs] = psi;
+    }
+}
+
+// The controls of the families whose candidates do not read the rolled state (lattice, ramp-hold, table), step by step, with
+// (sin, cos)(beta_k): rollout_one's statements for them (its control block and slip_trig), for the wave that rolls the Cartesian
+// rows beside the Frenet pieces.
+template <int CAND>
+struct StepControls {
+    const KP& P;
+    const Scenario<double>& S;
+    const double* table;
+    int cidx;
+    double a, df, da, ddf, lr_ratio;
+    __device__ __forceinline__ StepControls(const KP& P_, const Scenario<double>& S_, int c, const double* t)
+        : P(P_), S(S_), table(t), cidx(c), a(S_.a_prev), df(S_.df_prev), da(0.0), ddf(0.0), lr_ratio(P_.lr_ratio) {
+        const int i = cidx / P.G, j = cidx - i * P.G;
+        if (CAND == CAND_LATTICE) {
+            da = -P.rate_a + (2 * P.rate_a) * (double)i / (double)(P.G - 1);
+            ddf = steer_column<CAND>(P, S, j);
+        } else if (CAND == CAND_RAMP_HOLD) {
+            da = S.cpar[0] + cand_m(i, P.G, P.refine_it == 0) * S.cpar[2];
+            ddf = S.cpar[1] + cand_m(j, P.G, P.refine_it == 0) * S.cpar[3];
+        }
+    }
+    __device__ __forceinline__ void operator()(int k, double& a_out, double& sb, double& cb) {
+        if (CAND == CAND_LATTICE) {
+            a = clampd(a + da, P.a_min, P.a_max);
+            df = steer_next<CAND>(P, S, k, ddf, df);
+        } else if (CAND == CAND_RAMP_HOLD) {
+            double ba, bdf;
+            ramp_base<double>(S.ws, P.N, k, S.a_prev, S.df_prev, ba, bdf);
+            const double ta = clampd(ba + da, P.a_min, P.a_max);
+            a = clampd(a + clampd(ta - a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
+            df = steer_next<CAND>(P, S, k, ddf, df);
+        } else {
+            a = table[((size_t)cidx * 2 + 0) * P.N + k];
+            df = table[((size_t)cidx * 2 + 1) * P.N + k];
+        }
+        slip_trig<CAND>(P, lr_ratio, df, sb, cb);
+        a_out = a;
+    }
+};
 
 }  // namespace f64
 }  // namespace igt

@@ -45,6 +45,7 @@ struct StoreSink {
     __device__ __forceinline__ void ctrl(int, int k, double a, double df) {
         if (u) { u[k] = (T)a; u[N + k] = (T)df; }
     }
+    __device__ __forceinline__ void slip(int, int, double, double) {}
     __device__ __forceinline__ void state(int, int k, const double (&st)[7]) {
         if (x) {
 #pragma unroll
@@ -65,6 +66,7 @@ struct CaptureSink {
         base[(size_t)(7 * N1 + k) * 64] = a;
         base[(size_t)(8 * N1 + k) * 64] = df;
     }
+    __device__ __forceinline__ void slip(int, int, double, double) {}
     __device__ __forceinline__ void state(int, int k, const double (&st)[7]) {
 #pragma unroll
         for (int i = 0; i < 7; ++i) base[(size_t)(i * N1 + k) * 64] = st[i];

@@ -229,6 +229,14 @@ __device__ __forceinline__ unsigned long long* incumbents_of(const KP& P, int B,
     return (CAND == CAND_TRACK && !VALUE && (P.dev & DEV_LIVE_ROWS) && !(P.dev & (DEV_NO_BOUND | 262144)))
                ? reinterpret_cast<unsigned long long*>(part_J + (size_t)B * W) + B : nullptr;
 }
+// launch-time bit of KP::dev: the search pass leaves the unit winners' horizon checkpoints behind the incumbents
+// ([B W][CK_RECORD] doubles) for emit_seg_f64_kernel
+constexpr int DEV_CKPT = 1 << 29;
+constexpr int DEV_NO_SEG_EMIT = 16777216;   // IGT_DEV_FLAGS: emit re-rolls the winner in one piece (A/B runs, bitwise test)
+constexpr int CK_RECORD = (f64::CK_PARTS - 1) * f64::CK_FIELDS;
+__device__ __forceinline__ double* checkpoints_of(const KP& P, int B, int W, double* part_J) {
+    return (P.dev & DEV_CKPT) ? part_J + (size_t)B * W + 2 * (size_t)B : nullptr;
+}
 // queue items in unit-rank-major order when the tracking family's incumbents are in use and no order table was built
 __device__ __forceinline__ bool rank_major_items(const KP& P, int cand, bool value) {
     return cand == CAND_TRACK && !value && (P.dev & DEV_LIVE_ROWS) && !(P.dev & (DEV_NO_BOUND | 262144));
@@ -256,7 +264,8 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
                                               uint32_t* __restrict__ rec_viol, unsigned* __restrict__ rec_count,
                                               int32_t* __restrict__ rec_b, int2* __restrict__ unit_seg,
                                               const unsigned long long* __restrict__ row_mask = nullptr,
-                                              double* __restrict__ traj = nullptr, unsigned long long* inc_all = nullptr) {
+                                              double* __restrict__ traj = nullptr, unsigned long long* inc_all = nullptr,
+                                              double* __restrict__ ck_all = nullptr) {
     const int lane = threadIdx.x & 63;
     unsigned long long* inc = inc_all ? inc_all + b : nullptr;
     const UnitLayout L = unit_layout(P, W, CAND, row_mask ? row_mask[b] : ~0ull);
@@ -277,6 +286,7 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
     if (L.kind >= 2) unit_columns(P, L, p, r_first, nj);
     double J, sN, vN;
     unsigned viol;
+    double* ck_lds = nullptr;
     if constexpr (CAPTURE) {      // small batches: every lane's trajectory is kept for emit_gather_f64_kernel (all rows, so no
                                   // Cartesian skip; same arithmetic as below, same bits)
         CaptureSink keep{traj + (size_t)(b * W + p) * traj_unit_doubles(P.N) + lane, P.N + 1};
@@ -295,20 +305,25 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
     // 70 % of the benchmark's scenarios: the other vehicle is out of reach over the whole horizon (or filter_preds moved it
     // away), so the unit rolls without the Cartesian rows -- a sixth of the control step's instructions
     const bool far = !(P.dev & 65536) && obstacles_out_of_reach<double>(P, S, lane);
+    // horizon checkpoints of every lane in LDS (igt_fast64.h SEGMODE 1); the unit winner's go to HBM below
+    constexpr int SM = VALUE ? 0 : 1;
+    constexpr int CKF = CAND == CAND_TRACK ? 8 : 5;
+    __shared__ double ckl[VALUE ? 1 : (f64::CK_PARTS - 1) * CKF * 64];
+    ck_lds = (!VALUE && ck_all) ? ckl + lane : nullptr;
     if (L.kind >= 2 && steer_table_fits(P, W, CAND)) {
         __shared__ double stab[f64::STAB_MAX_ENTRIES * 3];
         f64::fill_steer_table<CAND>(P, S, nj, r_first, lane, P.lr_ratio, stab);
         if (far)
-            f64::rollout_one<CAND, HI, true, true, NullSink, true, true, NRK, false>(P, S, c, table, cinf, sink, J, viol, sN, vN,
-                                                                                     stab + col * 3, nj * 3);
+            f64::rollout_one<CAND, HI, true, true, NullSink, true, true, NRK, false, SM>(P, S, c, table, cinf, sink, J, viol, sN, vN,
+                                                                                         stab + col * 3, nj * 3, nullptr, ck_lds);
         else
-            f64::rollout_one<CAND, HI, true, true, NullSink, true, true, NRK, true>(P, S, c, table, cinf, sink, J, viol, sN, vN,
-                                                                                    stab + col * 3, nj * 3);
+            f64::rollout_one<CAND, HI, true, true, NullSink, true, true, NRK, true, SM>(P, S, c, table, cinf, sink, J, viol, sN, vN,
+                                                                                        stab + col * 3, nj * 3, nullptr, ck_lds);
         __syncthreads();                                  // the next unit of this wave rewrites the table
     } else if (far) {
-        f64::rollout_one<CAND, HI, true, true, NullSink, true, false, NRK, false>(P, S, c, table, cinf, sink, J, viol, sN, vN, nullptr, 0, inc);
+        f64::rollout_one<CAND, HI, true, true, NullSink, true, false, NRK, false, SM>(P, S, c, table, cinf, sink, J, viol, sN, vN, nullptr, 0, inc, ck_lds);
     } else {
-        f64::rollout_one<CAND, HI, true, true, NullSink, true, false, NRK, true>(P, S, c, table, cinf, sink, J, viol, sN, vN, nullptr, 0, inc);
+        f64::rollout_one<CAND, HI, true, true, NullSink, true, false, NRK, true, SM>(P, S, c, table, cinf, sink, J, viol, sN, vN, nullptr, 0, inc, ck_lds);
     }
     }
     if (VALUE) {   // terminal value network (mpc.py:369): append the feasible candidates for value_mfma_f64_kernel; the
@@ -337,6 +352,14 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
         const bool take = (oC >= 0) && (bestC < 0 || oJ < bestJ || (oJ == bestJ && oC < bestC));
         if (take) { bestJ = oJ; bestC = oC; }
     }
+    if (ck_lds && bestC >= 0 && c == bestC) {          // the unit winner's lane: its checkpoints -> HBM, record [q][field]
+        constexpr int CKF2 = CAND == CAND_TRACK ? 8 : 5;
+        double* g = ck_all + (size_t)(b * W + p) * CK_RECORD;
+#pragma unroll
+        for (int q = 0; q < f64::CK_PARTS - 1; ++q)
+#pragma unroll
+            for (int f = 0; f < CKF2; ++f) g[q * f64::CK_FIELDS + f] = ck_lds[(size_t)(q * CKF2 + f) * 64];
+    }
     if (lane == 0) {
         part_J[b * W + p] = bestJ; part_c[b * W + p] = bestC;
         // the unit's best feasible cost is the scenario's incumbent from now on (device-scope atomic: the later units of the
@@ -352,7 +375,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
         search_unit64<CAND, HI, VALUE, NRK>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN,
                                        rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg, live_rows_of(P, B, W, part_J), nullptr,
-                                       incumbents_of<CAND, VALUE>(P, B, W, part_J));
+                                       incumbents_of<CAND, VALUE>(P, B, W, part_J), checkpoints_of(P, B, W, part_J));
     }, rank_major_items(P, CAND, VALUE));
 }
 template <int CAND, bool HI, bool VALUE, int NRK>      // held to 256 registers for the tracking family (see search_fast_kernel_o2w)
@@ -360,7 +383,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
         search_unit64<CAND, HI, VALUE, NRK>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN,
                                        rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg, live_rows_of(P, B, W, part_J), nullptr,
-                                       incumbents_of<CAND, VALUE>(P, B, W, part_J));
+                                       incumbents_of<CAND, VALUE>(P, B, W, part_J), checkpoints_of(P, B, W, part_J));
     }, rank_major_items(P, CAND, VALUE));
 }
 // small batches (captures_trajectories): the same search, every unit also leaves its 64 trajectories in `traj`
@@ -461,6 +484,108 @@ __global__ __launch_bounds__(64) void emit_f64_kernel(KP P, int B, int W, const 
     f64::rollout_one<CAND, HI, false, false, StoreSink<double>, false, false, NRK>(P, S, c, table, cinf, sink, J, viol, sN, vN);
 }
 
+// ---- emit in pieces (batches that do not keep trajectories; progress cost) ----
+// One roll-out is a serial chain, and a wave issues a float64 instruction every four cycles however few of its lanes are
+// active: emit_f64_kernel's 64 waves at B = 4096 take one roll-out of time, 51 us.  Here a workgroup of four waves owns S
+// scenarios (lane = scenario): wave w rolls steps [w N / 4, (w + 1) N / 4) of each winner's Frenet rows from the checkpoint the
+// search pass left (igt_fast64.h SEGMODE 2) into LDS -- states, controls and (sin, cos)(beta_k) -- , then the first wave rolls the
+// Cartesian rows x, y, psi from those controls (cartesian_rows), and the workgroup writes its scenarios' x*[7, N+1] and u*[2, N]
+// out of LDS as they lie in HBM: contiguous, every store of a wave a full line (emit_f64_kernel: one lane per scenario,
+// 64 lines touched per store instruction, 2.6x the bytes at B = 65 536).  The same statements on the same numbers as the
+// roll-out in one piece: bit-identical (tests: against IGT_DEV_FLAGS = 16777216 and against rollout-all).
+struct SegSink {
+    static constexpr bool kKeepsStates = true;
+    double* X;      // this scenario's [7][N+1] in LDS
+    double* U;      // [2][N]
+    double* SB;     // [N] sin beta_k
+    double* CB;     // [N] cos beta_k
+    int N1;
+    __device__ __forceinline__ void ctrl(int, int k, double a, double df) { U[k] = a; U[N1 - 1 + k] = df; }
+    __device__ __forceinline__ void slip(int, int k, double sb, double cb) { SB[k] = sb; CB[k] = cb; }
+    __device__ __forceinline__ void state(int, int k, const double (&st)[7]) {
+        X[2 * N1 + k] = st[2]; X[3 * N1 + k] = st[3]; X[4 * N1 + k] = st[4]; X[5 * N1 + k] = st[5];
+        if (k == 0) { X[0] = st[0]; X[N1] = st[1]; X[6 * N1] = st[6]; }
+    }
+};
+__host__ __device__ inline int seg_doubles_per_scenario(int N) { return 7 * (N + 1) + 4 * N; }
+
+struct LdsControls {         // tracking family: the controls of step k as the Frenet pieces left them in LDS
+    const double* A; const double* SB; const double* CB;
+    __device__ __forceinline__ void operator()(int k, double& a, double& sb, double& cb) const { a = A[k]; sb = SB[k]; cb = CB[k]; }
+};
+constexpr int SEG_THREADS = 320;      // four waves for the pieces + one for the Cartesian rows (idle in the tracking family's first phase)
+
+template <int CAND, bool HI, int NRK>
+__global__ __launch_bounds__(SEG_THREADS) void emit_seg_f64_kernel(KP P, int B, int W, int S, const double* __restrict__ x0,
+                                                           const double* __restrict__ u_prev, const double* __restrict__ kparams,
+                                                           const uint32_t* __restrict__ flags, const double* __restrict__ obs,
+                                                           const double* __restrict__ table, const double* __restrict__ cinf,
+                                                           Centre<double> cpar, const double* __restrict__ part_J,
+                                                           const int32_t* __restrict__ part_c, double* __restrict__ ck_all,
+                                                           double* __restrict__ cost_out, int32_t* __restrict__ argmin_out,
+                                                           int32_t* __restrict__ status_out, double* __restrict__ x_out,
+                                                           double* __restrict__ u_out) {
+    extern __shared__ double seg_lds[];
+    __shared__ int win[64];
+    const int N1 = P.N + 1, per = seg_doubles_per_scenario(P.N);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b0 = blockIdx.x * S, b = b0 + lane;
+    const bool active = lane < S && b < B;
+    double bestJ = 0.0;
+    int c = -1, pw = 0;
+    if (active) {
+        for (int w = 0; w < W; ++w) {      // (J, c) lexicographic: ties -> lowest candidate index whatever the slice order
+            const int cw = part_c[(size_t)b * W + w];
+            const double Jw = part_J[(size_t)b * W + w];
+            if (cw >= 0 && (c < 0 || Jw < bestJ || (Jw == bestJ && cw < c))) { bestJ = Jw; c = cw; pw = w; }
+        }
+        if (wave == 0) {
+            cost_out[b] = c >= 0 ? bestJ : (double)INFINITY;
+            argmin_out[b] = c;
+            status_out[b] = c >= 0 ? 0 : 1;
+            win[lane] = c;
+        }
+    }
+    double* blk = seg_lds + (size_t)(lane < S ? lane : 0) * per;
+    Scenario<double> Sc;
+    if (active && c >= 0) {
+        load_scenario<double>(Sc, P, b, x0, u_prev, kparams, flags, obs, cpar);
+        if (wave < f64::CK_PARTS) {
+            SegSink sink{blk, blk + 7 * N1, blk + 7 * N1 + 2 * P.N, blk + 7 * N1 + 3 * P.N, N1};
+            const int k0 = f64::ckpt_step(P.N, wave), k1 = f64::ckpt_step(P.N, wave + 1);
+            double* ck = wave > 0 ? ck_all + ((size_t)b * W + pw) * CK_RECORD + (size_t)(wave - 1) * f64::CK_FIELDS : nullptr;
+            double J, sN, vN;
+            unsigned viol;
+            f64::rollout_one<CAND, HI, false, false, SegSink, false, false, NRK, false, 2>(P, Sc, c, table, cinf, sink, J, viol, sN, vN,
+                                                                                           nullptr, 0, nullptr, ck, k0, k1);
+        } else if (CAND != CAND_TRACK) {      // beside the pieces: the Cartesian rows, the controls generated on the spot
+            f64::StepControls<CAND> ctl(P, Sc, c, table);
+            f64::cartesian_rows<HI, NRK>(P, Sc.x0[0], Sc.x0[1], Sc.x0[6], Sc.x0[5], ctl, blk, blk + N1, blk + 6 * N1, 1);
+        }
+    }
+    __syncthreads();
+    if (CAND == CAND_TRACK) {                  // behind the pieces: the steering is theirs to decide
+        if (wave == f64::CK_PARTS && active && c >= 0) {
+            LdsControls ctl{blk + 7 * N1, blk + 7 * N1 + 2 * P.N, blk + 7 * N1 + 3 * P.N};
+            f64::cartesian_rows<HI, NRK>(P, Sc.x0[0], Sc.x0[1], Sc.x0[6], Sc.x0[5], ctl, blk, blk + N1, blk + 6 * N1, 1);
+        }
+        __syncthreads();
+    }
+    // the workgroup's scenarios as they lie in HBM (is_opt False, mpc.py:402-406: NaN)
+    const int nS = B - b0 < S ? B - b0 : S, nx = 7 * N1, nu = 2 * P.N;
+    double* xo = x_out + (size_t)b0 * nx;
+    double* uo = u_out + (size_t)b0 * nu;
+    for (int i = threadIdx.x; i < nS * nx; i += SEG_THREADS) {
+        const int sc = i / nx, r = i - sc * nx;
+        xo[i] = win[sc] >= 0 ? seg_lds[(size_t)sc * per + r] : (double)NAN;
+    }
+    for (int i = threadIdx.x; i < nS * nu; i += SEG_THREADS) {
+        const int sc = i / nu, r = i - sc * nu;
+        uo[i] = win[sc] >= 0 ? seg_lds[(size_t)sc * per + nx + r] : (double)NAN;
+    }
+}
+
 template <int CAND, bool HI>
 __global__ __launch_bounds__(256) void rollout_all_f64_kernel(KP P, int B, const double* __restrict__ x0,
                                                               const double* __restrict__ u_prev,
@@ -511,6 +636,7 @@ struct LdsSink {
     double* u;   // [2, N]
     int N;
     __device__ __forceinline__ void ctrl(int, int k, double a, double df) { u[k] = a; u[N + k] = df; }
+    __device__ __forceinline__ void slip(int, int, double, double) {}
     __device__ __forceinline__ void state(int, int k, const double (&st)[7]) {
 #pragma unroll
         for (int i = 0; i < 7; ++i) x[i * (N + 1) + k] = st[i];
@@ -625,6 +751,26 @@ bool search_is_static(const KP& P, int B, const SolveArgs<double>& A) {
     return captures_trajectories(P, A) && (size_t)B * (P.C / 64) <= (size_t)A.n_cu * 4 && !(P.dev & (256 | 1048576));
 }
 
+// Whether emit rolls the winner in four pieces from the search pass's checkpoints (emit_seg_f64_kernel): progress cost (with the
+// value network the winner is only known after the network has run), batches that do not keep trajectories, horizons of at
+// least 8 steps, workspace sized for the records (A.ck_ok).  The search launcher and the emit launcher both ask this.
+// scenarios per workgroup: a full wave's 64 when their staging fits a compute unit's LDS (116 KB at N = 20; 160 KB per CU,
+// the kernel asks for more than the default 64 KB: seg_lds_opt_in), else the largest power of two that does
+constexpr size_t SEG_LDS_MAX = 150 * 1024;
+static int seg_scenarios_per_block(const KP& P) {
+    int S = 64;
+    while (S > 0 && (size_t)S * seg_doubles_per_scenario(P.N) * 8 > SEG_LDS_MAX) S >>= 1;
+    return S;
+}
+template <class K>
+static hipError_t seg_lds_opt_in(K kernel) {      // once per instantiation and device (a function attribute)
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEG_LDS_MAX);
+}
+static bool emits_in_pieces(const KP& P, const SolveArgs<double>& A) {
+    return A.ck_ok && P.cost_mode == 0 && P.N >= 8 && !captures_trajectories(P, A) && seg_scenarios_per_block(P) >= 4 &&
+           !(P.dev & (32 | 1024 | 2048 | DEV_NO_SEG_EMIT));
+}
+
 // Whether the search runs on units made of live acceleration rows only (accel_rows_kernel; unit_layout).  Only for batches of
 // more than two rounds of units (B > 1024 at 256 candidates): below that the solve lasts as long as its longest unit, fewer
 // units do not shorten it, and the extra launch costs 8 us (a closed loop of 512 problems per step: 0.30 against 0.28 ms).
@@ -662,6 +808,7 @@ static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A
     // the live-row masks live behind the partials (part_J[B W ..]): no further kernel argument -- the search kernels spill
     // scalar registers as it is, and every one more shows up as v_readlane in the control-step loop
     KP Pr = P;
+    if (!VALUE && emits_in_pieces(P, A)) Pr.dev |= DEV_CKPT;
     const unsigned long long* rows = nullptr;
     if constexpr (CAND != CAND_TABLE) {
         if (packs_live_rows(P, B, A)) {
@@ -738,6 +885,31 @@ static hipError_t launch_emit64(const KP& P, int B, int W, const SolveArgs<doubl
     if (!HI && captures_trajectories(P, A)) {
         hipLaunchKernelGGL((emit_gather_f64_kernel<CAND>), dim3(B), dim3(64), 0, st, P, B, W, A.part_J, A.part_c, A.traj, A.cost_out,
                            A.argmin_out, A.status_out, A.x_out, A.u_out);
+        return hipGetLastError();
+    }
+    if (emits_in_pieces(P, A)) {
+        const int S = seg_scenarios_per_block(P);
+        const size_t lds = (size_t)S * seg_doubles_per_scenario(P.N) * 8;
+        double* ck = A.part_J + (size_t)B * W + 2 * (size_t)B;
+        {   // dynamic LDS above 64 KB has to be asked for, once per kernel and device
+            static bool asked[2][16] = {};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            const int which = (NRK4 == 4 && P.n_rk4 == 4) ? 0 : 1;
+            if (dev >= 0 && dev < 16 && !asked[which][dev]) {
+                const hipError_t e = which == 0 ? seg_lds_opt_in(emit_seg_f64_kernel<CAND, HI, NRK4>) : seg_lds_opt_in(emit_seg_f64_kernel<CAND, HI, 0>);
+                if (e != hipSuccess) return e;
+                asked[which][dev] = true;
+            }
+        }
+        if (NRK4 == 4 && P.n_rk4 == 4)
+            hipLaunchKernelGGL((emit_seg_f64_kernel<CAND, HI, NRK4>), dim3((B + S - 1) / S), dim3(SEG_THREADS), lds, st, P, B, W, S, A.x0, A.u_prev,
+                               A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, ck, A.cost_out, A.argmin_out,
+                               A.status_out, A.x_out, A.u_out);
+        else
+            hipLaunchKernelGGL((emit_seg_f64_kernel<CAND, HI, 0>), dim3((B + S - 1) / S), dim3(SEG_THREADS), lds, st, P, B, W, S, A.x0, A.u_prev,
+                               A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, ck, A.cost_out, A.argmin_out,
+                               A.status_out, A.x_out, A.u_out);
         return hipGetLastError();
     }
     if (NRK4 == 4 && P.n_rk4 == 4)

@@ -563,7 +563,7 @@ def test_production_kernel_switches_change_nothing(igt, dtype, cand, monkeypatch
     npdt = np.float64 if dtype == 'f64' else np.float32
     b = _batch(1536, npdt)
     outs = {}
-    for flag in (0, 1, 2, 4, 16, 512, 262144, 2097152, 8388608, 1 | 2 | 4 | 16 | 512, 4 | 2097152):
+    for flag in (0, 1, 2, 4, 16, 512, 262144, 2097152, 8388608, 16777216, 1 | 2 | 4 | 16 | 512, 4 | 2097152):
         monkeypatch.setenv('IGT_DEV_FLAGS', str(flag))
         with igt.BatchSolver(dtype=dtype, cand_mode=cand) as s:
             s.set_cinf(*_cinf())
@@ -629,6 +629,49 @@ def test_units_of_live_acceleration_rows_change_nothing(igt, golden_dir, cand, N
         for k in ('x', 'u', 'cost', 'argmin', 'status'):
             for o in outs[1:]:
                 assert np.array_equal(outs[0][k], o[k], equal_nan=True), (cost_mode, k)
+
+
+@pytest.mark.parametrize('cand,N,n_rk4,C,B', [('lattice', 20, 4, 256, 4096), ('track', 20, 4, 256, 4096), ('ramp_hold', 20, 4, 256, 1500),
+                                              ('table', 20, 4, 256, 700), ('track', 40, 4, 256, 900), ('lattice', 13, 3, 64, 2100),
+                                              ('track', 9, 2, 1024, 300), ('ramp_hold', 64, 4, 256, 500), ('lattice', 8, 4, 256, 8200)])
+def test_emit_in_pieces_is_the_emit_in_one_piece(igt, cand, N, n_rk4, C, B, monkeypatch):
+    """Batches that do not keep trajectories emit the winner in four pieces of the horizon, each resumed from a checkpoint the
+    search pass left (igt_fast64.h SEGMODE; emit_seg_f64_kernel), the Cartesian rows rolled on their own from the controls, the
+    outputs written as contiguous lines.  With IGT_DEV_FLAGS = 16777216 emit_f64_kernel rolls the winner in one piece as before:
+    the same x, u, cost, arg-min, status bit for bit -- every family, horizons that are and are not multiples of four, both
+    sub-step builds, the coarse discretisation's long polynomials, warm starts and a refinement pass, 1 to 16 units per
+    scenario; and the winner's trajectory is rollout-all's for the same candidate, bit for bit."""
+    rng = np.random.default_rng(3)
+    b = _batch(B, np.float64, N=N)
+    table = None
+    if cand == 'table':
+        a, d = np.meshgrid(np.linspace(-0.25, 0.25, 16), np.linspace(-0.04, 0.04, 16), indexing='ij')
+        table = np.ascontiguousarray(np.stack([a.ravel(), d.ravel()], axis=1)[:, :, None] * np.ones(N) + 1e-3 * rng.normal(size=(256, 2, N)))
+    flags, u_prev, u_ws = b['flags'], b['u_prev'], None
+    if cand in ('ramp_hold', 'track'):
+        prev = O.candidates_lattice(b['u_prev'], O.Params(N=N))[np.arange(B), (np.arange(B) * 37) % 256]
+        u_ws = np.ascontiguousarray(O.shift_controls(prev))
+        u_prev = np.ascontiguousarray(prev[:, :, 0])
+        flags = flags | np.where(np.arange(B) % 3 != 0, 2, 0).astype(np.uint32)
+    outs, alls = [], None
+    for flag in ('0', '16777216'):
+        monkeypatch.setenv('IGT_DEV_FLAGS', flag)
+        with igt.BatchSolver(N=N, n_rk4=n_rk4, C=C, dtype='f64', cand_mode=cand, refine_iters=1 if cand == 'ramp_hold' else 0) as s:
+            s.set_cinf(*_cinf())
+            if table is not None:
+                s.set_candidate_table(table)
+            outs.append(s.solve(b['x0'], u_prev, b['kparams'], flags, b['obs_xy'], u_ws=u_ws))
+            if flag == '0' and cand != 'ramp_hold':      # (a refinement pass re-centres the candidates: rollout-all rolls the first pass)
+                alls = s.rollout_all(b['x0'][:48], u_prev[:48], b['kparams'][:48], flags[:48], b['obs_xy'][:48], u_ws=None if u_ws is None else u_ws[:48])
+    monkeypatch.delenv('IGT_DEV_FLAGS')
+    assert (outs[0]['status'] == 0).any() and (outs[0]['status'] == 1).any()
+    for k in ('x', 'u', 'cost', 'argmin', 'status'):
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+    if alls is not None:
+        for i in range(48):
+            cw = outs[0]['argmin'][i]
+            if cw >= 0:
+                assert np.array_equal(outs[0]['x'][i], alls['X'][i, cw]) and np.array_equal(outs[0]['u'][i], alls['U'][i, cw]), i
 
 
 @pytest.mark.parametrize('cand,N', [('lattice', 20), ('track', 20), ('ramp_hold', 20), ('track', 40), ('table', 20)])
