@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SIMDS = 256 * 4                # 256 CUs x 4 SIMDs
 PEAK_CLOCK_GHZ = 2.4           # MI355X_MICROARCH.md: peak engine clock
 N_HORIZON, N_CAND = 20, 256
-PROFILE_ROUND = 'r03'          # profiles/<round>_pmc_*.json: the rocprofv3 --pmc passes of this command (tools/collect.sh)
+PROFILE_ROUND = 'r04'          # profiles/<round>_pmc_*.json: the rocprofv3 --pmc passes of this command (tools/collect.sh)
 
 
 def default_batch(n_gpus, gt=0):

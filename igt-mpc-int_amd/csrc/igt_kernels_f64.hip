@@ -766,9 +766,13 @@ template <class K>
 static hipError_t seg_lds_opt_in(K kernel) {      // once per instantiation and device (a function attribute)
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEG_LDS_MAX);
 }
+// Not when the caller overlaps solves (igt_set_concurrency >= 3): there the emit pass of one solve runs under the search pass of
+// another, its latency is hidden, and what matters is that it gets on the chip between two persistent search kernels -- one
+// 64-thread wave without LDS does, a 320-thread workgroup with 116 KB of LDS waits for a compute unit to drain (measured on one
+// box, three runs each: 20.3 against 20.9 M solves/s with four solves in flight).
 static bool emits_in_pieces(const KP& P, const SolveArgs<double>& A) {
     return A.ck_ok && P.cost_mode == 0 && P.N >= 8 && !captures_trajectories(P, A) && seg_scenarios_per_block(P) >= 4 &&
-           !(P.dev & (32 | 1024 | 2048 | DEV_NO_SEG_EMIT));
+           A.waves_per_simd != 1 && !(P.dev & (32 | 1024 | 2048 | DEV_NO_SEG_EMIT));
 }
 
 // Whether the search runs on units made of live acceleration rows only (accel_rows_kernel; unit_layout).  Only for batches of

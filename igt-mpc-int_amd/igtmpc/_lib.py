@@ -96,6 +96,8 @@ def load(dev=None):
     if dev in _libs:
         return _libs[dev]
     path = LIB_PATH_DEV if dev else LIB_PATH
+    if not dev and os.environ.get('IGT_LIB_PATH'):      # A/B runs against another build of the same ABI (tools/ab_lib.sh)
+        path = os.environ['IGT_LIB_PATH']
     if not os.path.exists(path):
         raise ImportError(f'{path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                           f'or `make -C igt-mpc-int_amd/csrc`')

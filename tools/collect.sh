@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box: the round's evidence in one call -- the rocprofv3 passes behind profiles/, then bench lines and probes.
-#   usage: tools/collect.sh <tag> [round=r03] [what=all|pmc|bench|probes]     then, back home:  python tools/publish.py <tag> <round>
-TAG=${1:-r03}
-ROUND=${2:-r03}
+#   usage: tools/collect.sh <tag> [round=r04] [what=all|pmc|bench|probes]     then, back home:  python tools/publish.py <tag> <round>
+TAG=${1:-r04}
+ROUND=${2:-r04}
 WHAT=${3:-all}
 export TMPDIR=/tmp
 O=gpurun_out

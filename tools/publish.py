@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Copies what tools/collect.sh <tag> left under gpurun_out/ into profiles/ under the names DESIGN.md cites.
-usage: publish.py <tag> [round=r03]"""
+usage: publish.py <tag> [round=r04]"""
 import glob, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else 'r03'
+rnd = sys.argv[2] if len(sys.argv) > 2 else 'r04'
 G, P = os.path.join(ROOT, 'gpurun_out'), os.path.join(ROOT, 'profiles')
 def cp(src, dst):
     s = os.path.join(G, src)
