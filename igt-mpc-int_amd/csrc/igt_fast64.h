@@ -406,6 +406,10 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
                                             const unsigned long long* inc = nullptr, double* ck = nullptr, int seg_k0 = 0,
                                             int seg_k1 = 0) {
     constexpr bool BOUND = CAND == CAND_TRACK && BOOK && UNIFORM && EARLY_EXIT;
+    // search on units of live acceleration rows (igt_kernels_f64.hip accel_rows_kernel; launch-time bit 30 of KP::dev): the speed
+    // box and the terminal set read the row's (a, v) recurrence alone and were judged there, with these statements -- every lane
+    // that holds a candidate holds one of a row that passed: not judged again (74 half-planes per lane at the last step)
+    const bool rows_judged = BOOK && EARLY_EXIT && UNIFORM && CAND != CAND_TABLE && (P.dev & (1 << 30)) != 0;
     constexpr int CKF = CAND == CAND_TRACK ? 8 : 5;            // fields this family writes
     constexpr bool KEEP_PSI = Sink::kKeepsStates;
     // search only needs feasible-or-not: |ey|, box v and collision are folded into one running maximum, compared with
@@ -555,12 +559,12 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
             J = J + ey * ey;
             if (LEAN) {
                 gmax = fmax(gmax, fabs(ey) - P.ey_lim);                              // mpc.py:296-299
-                gmax = fmax(gmax, fmax(P.v_min - v, v - P.v_max));                   // mpc.py:316-317 (k < N)
+                if (!rows_judged) gmax = fmax(gmax, fmax(P.v_min - v, v - P.v_max)); // mpc.py:316-317 (k < N)
             } else {
                 if (fabs(ey) - P.ey_lim > P.tol) viol |= VIOL_EY;
                 if (fmax(P.v_min - v, v - P.v_max) > P.tol) viol |= VIOL_BOX_V;
             }
-            if (k == P.N - 1) viol |= terminal_viol(P, v, a, cinf);                  // mpc.py:177-180
+            if (k == P.N - 1 && !rows_judged) viol |= terminal_viol(P, v, a, cinf);  // mpc.py:177-180
         }
         w.ey = ey; w.v1 = v;
         // unused on straight routes; with one scenario per lane the votes of substeps() read them on every lane
