@@ -365,7 +365,7 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
                             (value ? (size_t)B * igt::VN_H * sizeof(T) + (size_t)B * Wk * 8 + (size_t)B * 8 + n_rec * 4 + 512 : 0) + 20 * 256;
         if (int rc = ensure_work(h, need, st)) return rc;
         Arena wa{(char*)h->d_work, 0};
-        A.part_J = wa.take<double>((size_t)B * W + (sizeof(T) == 8 ? (size_t)2 * B : 0) + ck_doubles);  // double path: + [B] live-row masks + [B] incumbents + checkpoint records (igt_kernels_f64.hip)
+        A.part_J = wa.take<double>((size_t)B * W + (sizeof(T) == 8 ? (size_t)2 * B : (size_t)B) + ck_doubles);  // double path: + [B] live-row masks + [B] incumbents + checkpoint records (igt_kernels_f64.hip); float path: + [B] incumbents
         A.ck_ok = ck_ok;
         A.part_c = wa.take<int32_t>((size_t)B * W);
         d_cpar = wa.take<double>((size_t)B * 4);

@@ -349,6 +349,29 @@ __device__ __forceinline__ bool obstacles_out_of_reach(const KP& P, const Scenar
 
 
 
+// ---- the incumbent bound of the tracking family's search (igt_fast64.h rollout_one has the derivation) ----
+constexpr unsigned VIOL_PRUNED = 128u;            // internal to the search pass: never reported
+__device__ __forceinline__ unsigned long long cost_key(double J) {           // order-preserving map double -> u64
+    const unsigned long long b = (unsigned long long)__double_as_longlong(J);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double cost_of_key(unsigned long long k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
+// lam of the scenario, or 0: no usable bound (|kv| ey_b too close to 1)
+template <typename T>
+__device__ __forceinline__ double progress_slack(const KP& P, const Scenario<T>& S) {
+    const double vabs = fmax(fabs(P.v_min), fabs(P.v_max)) + P.tol + fmax(fabs(P.a_min), fabs(P.a_max)) * P.dt;
+    const double eyb = P.ey_lim + P.tol + 1.5 * P.dt * vabs;
+    const double q = fabs(S.kv) * eyb;
+    if (!(q < 0.5) || !(P.w_u >= 0.0)) return 0.0;                           // (a negative effort weight: stage terms of either sign)
+    const double lam = 1.0 / (1.0 - q);
+    const double reach = (P.N + 1) * P.dt * vabs * lam;                      // every stage argument stays within s_0 +- reach
+    const bool clear = S.kv == 0.0 || S.x0[2] + reach < S.b0 || S.x0[2] - reach >= S.b1;
+    return clear ? 1.0 : lam;
+}
+
+
 // what the candidate generators are centred on: refinement parameters [B,4] (null: first pass) and the batch's warm
 // starts [B,2,N] (null: none)
 template <typename T>

@@ -360,25 +360,7 @@ __device__ __forceinline__ void fill_steer_table(const KP& P, const Scenario<dou
 // search_unit64 publishes with an atomic min, units run highest acceleration rows first) -- cannot win and cannot tie: it is
 // marked lost.  The winner is never among them, so cost / arg-min / trajectory are what they were, bit for bit; only HOW MANY
 // steps a unit rolls depends on which incumbents it saw (tools/bound_prune_probe.py: 0.84 -> 0.46 of the wave-steps).
-constexpr unsigned VIOL_PRUNED = 128u;            // internal to the search pass: never reported
-__device__ __forceinline__ unsigned long long cost_key(double J) {           // order-preserving map double -> u64
-    const unsigned long long b = (unsigned long long)__double_as_longlong(J);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double cost_of_key(unsigned long long k) {
-    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
-}
-// lam of the scenario, or 0: no usable bound (|kv| ey_b too close to 1)
-__device__ __forceinline__ double progress_slack(const KP& P, const Scenario<double>& S) {
-    const double vabs = fmax(fabs(P.v_min), fabs(P.v_max)) + P.tol + fmax(fabs(P.a_min), fabs(P.a_max)) * P.dt;
-    const double eyb = P.ey_lim + P.tol + 1.5 * P.dt * vabs;
-    const double q = fabs(S.kv) * eyb;
-    if (!(q < 0.5) || !(P.w_u >= 0.0)) return 0.0;                           // (a negative effort weight: stage terms of either sign)
-    const double lam = 1.0 / (1.0 - q);
-    const double reach = (P.N + 1) * P.dt * vabs * lam;                      // every stage argument stays within s_0 +- reach
-    const bool clear = S.kv == 0.0 || S.x0[2] + reach < S.b0 || S.x0[2] - reach >= S.b1;
-    return clear ? 1.0 : lam;
-}
+// (VIOL_PRUNED, cost_key / cost_of_key, progress_slack: igt_device.h -- the float path prunes the same way)
 
 // XY = false (search only, decided per unit by obstacles_out_of_reach): x, y are neither integrated nor judged -- no candidate
 // that holds the speed box can come within d_min of any forecast position, and one that does not is infeasible already.

@@ -102,8 +102,23 @@ template <int CAND>
 __device__ __forceinline__ bool steering_slices(const KP& P, int W) {
     return CAND != CAND_TABLE && P.G * P.G == P.C && W * 128 == P.C && P.G % W == 0 && !(P.dev & 1);
 }
+// Tracking family (its steering is a feedback on the rolled state: its candidates fail on what the ACCELERATION row decides,
+// igt_kernels_f64.hip): unit p takes the G / W acceleration rows G-1 - p G/W downwards with all G steering offsets -- the rows
+// that make most progress in unit 0, whose best cost is the incumbent the later units are pruned against (igt_device.h,
+// igt_fast64.h BOUND).  A lane holds (row, j) and (row - 64 / G, j).  G in {16, 32, 64}; IGT_DEV_FLAGS = 262144: steering slices.
+constexpr int DEV_INCUMBENTS = 1 << 30;      // launch-time bit of KP::dev (float kernels): [B] incumbent keys behind the partials
+template <int CAND>
+__device__ __forceinline__ bool accel_units(const KP& P, int W) {
+    return CAND == CAND_TRACK && P.G * P.G == P.C && W * 128 == P.C && P.G >= 16 && P.G <= 64 && !(P.dev & (1 | 262144));
+}
 template <int CAND>
 __device__ __forceinline__ void slice_candidates(const KP& P, int W, int p, int lane, int (&cidx)[2]) {
+    if (accel_units<CAND>(P, W)) {
+        const int nr = P.G / W, j = lane % P.G, rl = lane / P.G, top = P.G - 1 - p * nr;
+        cidx[0] = (top - rl) * P.G + j;
+        cidx[1] = (top - rl - nr / 2) * P.G + j;
+        return;
+    }
     const int chunks = P.C / 64;
     // an odd number of 64-candidate chunks: the last slice rolls its chunk twice (harmless duplicate)
     cidx[0] = (2 * p) * 64 + lane;
@@ -117,6 +132,13 @@ __device__ __forceinline__ void slice_candidates(const KP& P, int W, int p, int 
 }
 template <int CAND>
 __device__ __forceinline__ void candidate_slot(const KP& P, int W, int c, int& p, int& slot) {   // slot = 64 q + lane
+    if (accel_units<CAND>(P, W)) {
+        const int i = c / P.G, j = c - i * P.G, nr = P.G / W, down = P.G - 1 - i;
+        p = down / nr;
+        const int d = down - p * nr, q = d >= nr / 2 ? 1 : 0;
+        slot = 64 * q + (d - q * (nr / 2)) * P.G + j;
+        return;
+    }
     if (steering_slices<CAND>(P, W)) {
         const int i = c / P.G, j = c - i * P.G, nj = P.G / W;
         const int r = j >= P.G / 2 ? 2 * (j - P.G / 2) : 2 * (P.G / 2 - 1 - j) + 1;
@@ -155,12 +177,17 @@ __device__ __forceinline__ void search_unit(const KP& P, int W, int b, int p, do
     double J[2], sN[2], vN[2];
     unsigned viol[2];
     const Ckpt ck{CKPT && ck_parts > 1 ? ckpt : nullptr, (size_t)n_units, gw, lane, ck_parts > 1 ? P.N / ck_parts : 0};
+    // the scenario's incumbent (tracking family, progress cost): [B] keys behind the [B W] partials
+    unsigned long long* inc = (CAND == CAND_TRACK && !VALUE && (P.dev & DEV_INCUMBENTS))
+                                  ? reinterpret_cast<unsigned long long*>(part_J + n_units) + b : nullptr;
     // units whose obstacles are out of every speed-feasible candidate's reach roll without the Cartesian rows (igt_device.h
     // obstacles_out_of_reach); the builds that leave checkpoints for emit need x, y
     if (!CKPT && !(P.dev & 65536) && obstacles_out_of_reach<float>(P, S, lane))
-        rollout_pair<CAND, HI, true, true, float, NullSink, true, false, false, false>(P, S, cidx, table, cinf, sink, J, viol, sN, vN, ck);
+        rollout_pair<CAND, HI, true, true, float, NullSink, true, false, false, false>(P, S, cidx, table, cinf, sink, J, viol, sN, vN, ck,
+                                                                                       Seg{0, 0, nullptr, 0}, inc);
     else
-        rollout_pair<CAND, HI, true, true, float, NullSink, true, CKPT>(P, S, cidx, table, cinf, sink, J, viol, sN, vN, ck);
+        rollout_pair<CAND, HI, true, true, float, NullSink, true, CKPT>(P, S, cidx, table, cinf, sink, J, viol, sN, vN, ck,
+                                                                        Seg{0, 0, nullptr, 0}, inc);
     if (VALUE) {   // terminal value network (mpc.py:369): append the feasible candidates for the value kernels
         const bool dup = cidx[1] == cidx[0];                       // odd chunk count: second half is a duplicate
         const bool ok0 = viol[0] == 0 && finite_d(J[0]), ok1 = viol[1] == 0 && finite_d(J[1]) && !dup;
@@ -187,7 +214,9 @@ __device__ __forceinline__ void search_unit(const KP& P, int W, int b, int p, do
     for (int q = 0; q < 2; ++q) {
         const double Jq = J[q] - (sN[q] - S.x0[2]);  // mpc.py:372
         const bool ok = (viol[q] == 0) && finite_d(Jq);
-        if (ok && (bestC < 0 || Jq < bestJ)) { bestJ = Jq; bestC = cidx[q]; }
+        // (J, c) lexicographic: the tracking family's units hold the higher row first, and rows clipped to the same envelope
+        // tie exactly -- the lowest index wins whatever the order
+        if (ok && (bestC < 0 || Jq < bestJ || (Jq == bestJ && cidx[q] < bestC))) { bestJ = Jq; bestC = cidx[q]; }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -196,7 +225,10 @@ __device__ __forceinline__ void search_unit(const KP& P, int W, int b, int p, do
         const bool take = (oC >= 0) && (bestC < 0 || oJ < bestJ || (oJ == bestJ && oC < bestC));
         if (take) { bestJ = oJ; bestC = oC; }
     }
-    if (lane == 0) { part_J[gw] = bestJ; part_c[gw] = bestC; }
+    if (lane == 0) {
+        part_J[gw] = bestJ; part_c[gw] = bestC;
+        if (inc && bestC >= 0) atomicMin(inc, cost_key(bestJ));      // the scenario's incumbent from now on (device scope)
+    }
 }
 
 // The same loop built twice: 3 waves per SIMD (168 VGPRs, a 128 B/lane spill around each unit) keeps the VALU ~90 %
@@ -217,7 +249,7 @@ __device__ __forceinline__ void search_waves_f32(IGT_SEARCH_ARGS) {
     search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
         search_unit<CAND, HI, VALUE, CKPT>(P, W, b, p, ckpt, ck_parts, B * W, x0, u_prev, kparams, flags, obs, table, cinf, cpar,
                                            part_J, part_c, rec_sN, rec_vN, rec_J, rec_viol, rec_count, rec_b);
-    });
+    }, CAND == CAND_TRACK && !VALUE && (P.dev & DEV_INCUMBENTS) != 0);      // unit-rank-major items: every unit 0 before any unit 1
 }
 #if IGT_DEV_KERNELS
 template <int CAND, bool HI, bool VALUE>
@@ -570,28 +602,38 @@ static hipError_t launch_search_fast(const KP& P, int B, const SolveArgs<float>&
     const size_t grid = total < slots ? total : slots;
     const unsigned* order = nullptr;
     const int order_stride = ((B + 7) / 8) * W;
+    KP Pr = P;
+    if constexpr (CAND == CAND_TRACK && !VALUE) {
+        // tracking family, progress cost: units of acceleration rows, pruned against the scenario's incumbent (igt_fast64.h
+        // BOUND).  The [B] keys behind the partials start every pass at "none" (all ones: above every cost's key).
+        if (P.G * P.G == P.C && W * 128 == P.C && P.G >= 16 && P.G <= 64 && !(P.dev & (1 | 262144 | 8388608)) && W > 1) {
+            hipError_t e = hipMemsetAsync(A.part_J + total, 0xff, (size_t)B * 8, st);
+            if (e != hipSuccess) return e;
+            Pr.dev |= DEV_INCUMBENTS;
+        }
+    }
     if (search_builds_queues(P, B, A)) {                     // small batches: longest units first
-        hipLaunchKernelGGL(build_queues_kernel<float>, dim3(8), dim3(QB_THREADS), 0, st, P, B, W, A.x0, A.kparams, A.queue_order,
+        hipLaunchKernelGGL(build_queues_kernel<float>, dim3(8), dim3(QB_THREADS), 0, st, Pr, B, W, A.x0, A.kparams, A.queue_order,
                            order_stride, A.work_counter);
         order = A.queue_order;
     }
 #if IGT_DEV_KERNELS
     if (o3)
-        hipLaunchKernelGGL((search_fast_kernel_o3<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
+        hipLaunchKernelGGL((search_fast_kernel_o3<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, Pr, B, W, 8, A.work_counter,
                            order, order_stride, A.ckpt, A.ck_parts, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, A.rec_sN,
                            A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
     else
 #endif
     if (A.ckpt && A.ck_parts > 1)
-        hipLaunchKernelGGL((search_fast_kernel_o2c<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
+        hipLaunchKernelGGL((search_fast_kernel_o2c<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, Pr, B, W, 8, A.work_counter,
                            order, order_stride, A.ckpt, A.ck_parts, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf,
                            A.centre(), A.part_J, A.part_c, A.rec_sN, A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
     else if constexpr (CAND == CAND_TRACK)
-        hipLaunchKernelGGL((search_fast_kernel_o2w<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
+        hipLaunchKernelGGL((search_fast_kernel_o2w<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, Pr, B, W, 8, A.work_counter,
                            order, order_stride, A.ckpt, A.ck_parts, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, A.rec_sN,
                            A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
     else
-        hipLaunchKernelGGL((search_fast_kernel_o2<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, P, B, W, 8, A.work_counter,
+        hipLaunchKernelGGL((search_fast_kernel_o2<CAND, HI, VALUE>), dim3(grid), dim3(64), 0, st, Pr, B, W, 8, A.work_counter,
                            order, order_stride, A.ckpt, A.ck_parts, A.x0, A.u_prev, A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, A.rec_sN,
                            A.rec_vN, A.rec_J, A.rec_viol, A.rec_count, A.rec_b);
     return hipGetLastError();

@@ -227,7 +227,8 @@ __global__ __launch_bounds__(QB_THREADS) void build_queues_kernel(KP P, int B, i
                 // float64 tracking units (row_mask given: cut along the acceleration axis, highest rows in unit 0): unit-rank-major
                 // -- every scenario's unit 0 before any unit 1 -- so that a later unit of a scenario starts when the earlier ones
                 // have left their best cost as its incumbent (igt_fast64.h BOUND)
-                if (P.cand_mode == CAND_TRACK && row_mask && !(P.dev & 262144)) c = W <= QC ? p : (p * QC) / W;
+                if (P.cand_mode == CAND_TRACK && (row_mask || (sizeof(T) == 4 && (P.dev & (1 << 30)))) && !(P.dev & 262144))
+                    c = W <= QC ? p : (p * QC) / W;
             }
         }
         cls[t] = c; rank[t] = 0;

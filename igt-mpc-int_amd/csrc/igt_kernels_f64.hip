@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void accel_rows_kernel(KP P, int B, const doub
     const unsigned long long m = __ballot(live);
     if (b < B && i == 0) {
         row_mask[b] = (m >> (lane & ~(P.G - 1))) & (P.G >= 64 ? ~0ull : ((1ull << P.G) - 1ull));
-        row_mask[B + b] = f64::cost_key((double)INFINITY);      // the scenario's incumbent of this pass: none yet (igt_fast64.h BOUND)
+        row_mask[B + b] = cost_key((double)INFINITY);      // the scenario's incumbent of this pass: none yet (igt_fast64.h BOUND)
     }
 }
 
@@ -364,7 +364,7 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
         part_J[b * W + p] = bestJ; part_c[b * W + p] = bestC;
         // the unit's best feasible cost is the scenario's incumbent from now on (device-scope atomic: the later units of the
         // scenario may run on another XCD)
-        if (inc && bestC >= 0) atomicMin(inc, f64::cost_key(bestJ));
+        if (inc && bestC >= 0) atomicMin(inc, cost_key(bestJ));
     }
 }
 

@@ -124,7 +124,8 @@ def test_solve_matches_oracle(igt, dtype, tol, eps, eps_tie):
 
 
 @pytest.mark.parametrize('B,cand_mode,dtype', [(64, 'lattice', 'f32'), (64, 'ramp_hold', 'f32'), (2304, 'lattice', 'f32'),
-                                               (64, 'lattice', 'f64'), (64, 'ramp_hold', 'f64'), (2304, 'lattice', 'f64')])
+                                               (64, 'lattice', 'f64'), (64, 'ramp_hold', 'f64'), (2304, 'lattice', 'f64'),
+                                               (64, 'track', 'f32'), (2304, 'track', 'f32'), (9000, 'track', 'f32'), (2304, 'track', 'f64')])
 def test_search_and_emit_agree_bitwise(igt, B, cand_mode, dtype):
     """emit re-rolls the winner with the arithmetic search used: the trajectory it stores must be exactly the
     rollout_all trajectory of that candidate.  f32: up to B = 2048 emit resumes four quarters of the horizon from the
@@ -553,7 +554,7 @@ def test_value_net_with_ramp_hold_refinement_f64(igt, golden_dir):
     assert rel_err(got['cost'][sol], ref['cost'][sol]).max() < 1e-9
 
 
-@pytest.mark.parametrize('dtype,cand', [('f64', 'lattice'), ('f64', 'track'), ('f32', 'lattice')])
+@pytest.mark.parametrize('dtype,cand', [('f64', 'lattice'), ('f64', 'track'), ('f32', 'lattice'), ('f32', 'track')])
 def test_production_kernel_switches_change_nothing(igt, dtype, cand, monkeypatch):
     """The A/B switches of the production kernels (IGT_DEV_FLAGS; VERDICT r2: "untested surface") only change HOW the work
     is laid out -- candidate slices in index order (1), no early exit (2), no steering table (4), no longest-first queues
