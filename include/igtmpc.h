@@ -297,8 +297,18 @@ int igt_allgather_controls_f64(igt_handle* h, int32_t B_local, const double* u_o
  * resident side by side and each one's waves run faster while the other's are being replaced (measured at B = 4096 with four
  * solves in flight: 0.187 -> 0.176 ms per step; one solve alone: 0.277 -> 0.324, hence a setting and not the default; with
  * two in flight the streams of this runtime end up on one hardware queue and run one after the other, so 2 is treated as 1).
+ * From 3 on, the float64 emit pass also stays one lean kernel (one wave per 64 scenarios, no LDS) instead of the five-wave,
+ * LDS-staged emit in pieces that a solve with the device to itself uses to cut the winner roll-out's latency: between two
+ * persistent search kernels only the lean one gets on the chip.
  * Results do not depend on it.  IGT_E_INVALID unless 1 <= solves_in_flight <= 64. */
 int igt_set_concurrency(igt_handle* h, int32_t solves_in_flight);
+
+/* Workspace (owned by the handle, grown on the first solve of a batch size, never shrunk; growth synchronises the stream and is
+ * refused under stream capture with IGT_E_STATE).  Per scenario, C = 256: 48 B of slice partials, 16 B of live-row masks and
+ * incumbent keys (float64; float32: 8 B), 768 B of horizon checkpoints of the unit winners (float64, progress cost, N >= 8),
+ * 288 B of queue order / counters; value-network cost: + 36 B per candidate (the list of feasible candidates).  Small float64
+ * batches (no more 64-candidate units than the device has SIMDs: B <= 256 at C = 256) keep every candidate's trajectory for
+ * the emit pass: 9 (N + 1) 64 doubles per unit = 97 KB per unit at N = 20, i.e. up to 99 MB per handle at B C / 64 = 1024. */
 
 /* Per-kernel timing with HIP events on the launch stream (used by bench.py for the
  * roofline line).  While enabled, every solve records events around its kernels;

@@ -328,7 +328,7 @@ def test_design_cites_profiles_that_exist_and_belong_together():
     assert not missing, missing
     m = re.search(r'kernel-source hash `([0-9a-f]{16})`', text)
     assert m, 'DESIGN.md must name the kernel-source hash of its profiles'
-    pm = glob.glob(os.path.join(ROOT, 'profiles', 'r03_pmc_*.json'))      # this round's counter summaries
+    pm = glob.glob(os.path.join(ROOT, 'profiles', 'r04_pmc_*.json'))      # this round's counter summaries
     assert len(pm) >= 6
     for f in pm:
         assert json.load(open(f))['source_hash'] == m.group(1), f

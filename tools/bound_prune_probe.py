@@ -130,3 +130,6 @@ for fam in ('lattice', 'track'):
                 tot += min(d.max() + 1, N)
                 Jinc = min(Jinc, np.where(feas[bi, g], J[bi, g], np.inf).min())
         print(f'top rows first, each unit sees the units before it (clear share {clear.mean():.2f}): executed', round(tot / (B * 4 * N), 3))
+        top = [np.where(feas[bi, units_of(bi)[-1]], J[bi, units_of(bi)[-1]], np.inf).min() == Jbest[bi] for bi in range(B)
+               if np.isfinite(Jbest[bi]) and units_of(bi)]
+        print('   share of scenarios whose winner is in the unit of the highest live rows:', round(float(np.mean(top)), 3))
