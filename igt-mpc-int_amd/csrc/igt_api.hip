@@ -765,6 +765,8 @@ int igt_create(const igt_params* p, int device, igt_handle** out) {
         e = hipEventCreate(&h->ev[i]);
         if (e != hipSuccess) { delete h; return fail(IGT_E_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
     }
+    e = igt::prepare_emit_kernels();
+    if (e != hipSuccess) { (void)igt_destroy(h); return fail(IGT_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
     *out = h;
     return IGT_OK;
 }

@@ -277,7 +277,10 @@ __device__ __forceinline__ void search_waves(const KP& P, int B, int W, int queu
     const unsigned n_scen = ((unsigned)B + 7u) / 8u;          // blocks of 8 scenarios; queue q takes one of each
     const unsigned K = n_scen * uW;
     const bool lane0 = (threadIdx.x & 63) == 0;
-    const unsigned hold = ((P.dev >> 12) & 15u ? (P.dev >> 12) & 15u : 4u) * (gridDim.x / (unsigned)queues + 1u);
+    // (round 4: 8 items per wave instead of 4 -- at B = 4096 that is every item, i.e. no index is fetched ahead: an item reserved
+    // by a wave that is 100 us into an arc unit starts when that unit ends, while waves go idle from 75 % of the span on;
+    // profiles/r04_hold_sweep.txt: search 0.228 -> 0.220 ms, one solve at a time 16.1 -> 16.7 M solves/s)
+    const unsigned hold = ((P.dev >> 12) & 15u ? (P.dev >> 12) & 15u : 8u) * (gridDim.x / (unsigned)queues + 1u);
     const unsigned late_from = K > hold ? K - hold : 0u;
     // own queue first, then the other XCDs' queues in turn (the XCDs are not equally fast: one of the eight took 10 %
     // longer over the same work in every trace).  Item k of a queue is scenario ordinal j and slice p, through the

@@ -895,17 +895,6 @@ static hipError_t launch_emit64(const KP& P, int B, int W, const SolveArgs<doubl
         const int S = seg_scenarios_per_block(P);
         const size_t lds = (size_t)S * seg_doubles_per_scenario(P.N) * 8;
         double* ck = A.part_J + (size_t)B * W + 2 * (size_t)B;
-        {   // dynamic LDS above 64 KB has to be asked for, once per kernel and device
-            static bool asked[2][16] = {};
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            const int which = (NRK4 == 4 && P.n_rk4 == 4) ? 0 : 1;
-            if (dev >= 0 && dev < 16 && !asked[which][dev]) {
-                const hipError_t e = which == 0 ? seg_lds_opt_in(emit_seg_f64_kernel<CAND, HI, NRK4>) : seg_lds_opt_in(emit_seg_f64_kernel<CAND, HI, 0>);
-                if (e != hipSuccess) return e;
-                asked[which][dev] = true;
-            }
-        }
         if (NRK4 == 4 && P.n_rk4 == 4)
             hipLaunchKernelGGL((emit_seg_f64_kernel<CAND, HI, NRK4>), dim3((B + S - 1) / S), dim3(SEG_THREADS), lds, st, P, B, W, S, A.x0, A.u_prev,
                                A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, ck, A.cost_out, A.argmin_out,
@@ -926,6 +915,23 @@ static hipError_t launch_emit64(const KP& P, int B, int W, const SolveArgs<doubl
                            A.x_out, A.u_out);
     return hipGetLastError();
 }
+// dynamic LDS above 64 KB has to be asked for, per kernel and device: once per handle at igt_create -- not on the launch path,
+// which must stay a pure sequence of stream operations (stream capture)
+template <int CAND>
+static hipError_t seg_opt_in_family() {
+    hipError_t e = seg_lds_opt_in(emit_seg_f64_kernel<CAND, false, 4>);
+    if (e == hipSuccess) e = seg_lds_opt_in(emit_seg_f64_kernel<CAND, false, 0>);
+    if (e == hipSuccess) e = seg_lds_opt_in(emit_seg_f64_kernel<CAND, true, 0>);
+    return e;
+}
+hipError_t prepare_emit_kernels() {
+    hipError_t e = seg_opt_in_family<CAND_LATTICE>();
+    if (e == hipSuccess) e = seg_opt_in_family<CAND_TABLE>();
+    if (e == hipSuccess) e = seg_opt_in_family<CAND_RAMP_HOLD>();
+    if (e == hipSuccess) e = seg_opt_in_family<CAND_TRACK>();
+    return e;
+}
+
 template <>
 hipError_t launch_emit<double>(const KP& P, int B, int W, const SolveArgs<double>& A, hipStream_t st) {
 #if IGT_DEV_KERNELS

@@ -69,6 +69,7 @@ template <typename T>
 hipError_t launch_value(const KP& P, int B, const DevNet<T>& net, const SolveArgs<T>& A, T* cost_all,
                         uint32_t* viol_all, hipStream_t st);
 hipError_t prepare_value_kernels(int n_hidden_mats);   // once per igt_set_value_net: dynamic-LDS function attributes
+hipError_t prepare_emit_kernels();                     // once per igt_create: the same for the float64 emit in pieces
 template <typename T> hipError_t launch_reduce(int B, int W, const SolveArgs<T>& A, hipStream_t st);
 // ramp-hold refinement: winner of the pass just finished -> centre/span of the next pass (cpar[B,4])
 template <typename T>
