@@ -475,8 +475,15 @@ def main():
             u0_buf = [torch.empty((Bm, 2), dtype=td, device=f'cuda:{dev}') for _ in range(F)]
             gathered = [torch.empty((Bm * world, 2), dtype=td, device=f'cuda:{dev}') for _ in range(F)]
         step_no = [0]
+        drain_hint = os.environ.get('IGT_BENCH_NO_DRAIN_HINT') != '1'      # A/B switch (tools only)
 
-        def step():
+        conc = [F] * F                    # what each handle was last told about the solves in flight
+
+        def step(in_flight_now=None):
+            # in_flight_now: how many solves are in flight once this one is enqueued, when the caller knows (the timed loop does:
+            # it enqueues exactly K steps and waits, so the last F - 1 steps see the pipeline drain) -- igt_set_concurrency is told,
+            # as include/igtmpc.h asks of a caller that overlaps solves (below 3 in flight a search takes two waves per SIMD again
+            # and the emit pass rolls in pieces: a solve with the device mostly to itself)
             # step t on handle / stream t mod F; the inputs are read-only, every lane has its own outputs and its own exchange
             # buffers.  The staging copy of u*[:, :, 0] and the all-gather are enqueued behind the lane's solve (the collective
             # itself runs on the process group's stream, which waits for the lane and which the lane waits for).  The search
@@ -486,6 +493,10 @@ def main():
             q = step_no[0] % F
             lane = lanes[q] if lanes[q] is not None else torch.cuda.current_stream(dev)
             step_no[0] += 1
+            want = F if in_flight_now is None else max(1, min(F, in_flight_now))
+            if want != conc[q] and drain_hint:
+                solvers[q].set_concurrency(want)
+                conc[q] = want
             with torch.cuda.stream(lane):
                 solvers[q].solve(*dargs, out=outs[q])
                 if exchange:
@@ -526,8 +537,8 @@ def main():
             step()
         fence()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        for i in range(steps):
+            step(in_flight_now=steps - i)      # the last F - 1 steps: fewer solves behind this one than lanes
         issued = time.perf_counter() - t0          # host time to enqueue the timed steps (close to `elapsed`: host-bound)
         fence()
         elapsed = time.perf_counter() - t0
@@ -563,6 +574,7 @@ def main():
         lane_s, lane_e = None, None
         if F > 1:
             for sv in solvers:
+                sv.set_concurrency(F)
                 sv.set_profiling(True)
             ls, le = [], []
             n_prof = max(4 * F, min(steps, 48))

@@ -617,8 +617,8 @@ def test_units_of_live_acceleration_rows_change_nothing(igt, golden_dir, cand, N
         # live rows, 64 per unit (tracking: + the incumbent bound); all rows; live rows in whole columns; (tracking:) no incumbent bound
         for flag in ('0', '2097152', '4194304') + (('8388608',) if cand == 'track' else ()):
             monkeypatch.setenv('IGT_DEV_FLAGS', flag)
-            with igt.BatchSolver(N=N, C=C, dtype='f64', cand_mode=cand, cost_mode=cost_mode,
-                                 refine_iters=1 if cand == 'ramp_hold' else 0) as s:
+            with igt.BatchSolver(N=N, C=C, dtype='f64', cand_mode=cand, cost_mode=cost_mode,     # (tracking at N = 40: with a refinement
+                                 refine_iters=1 if (cand == 'ramp_hold' or (cand == 'track' and N == 40)) else 0) as s:   # pass -- the incumbents restart)
                 s.set_cinf(*_cinf())
                 extra = ()
                 if cost_mode == 'value_net':
