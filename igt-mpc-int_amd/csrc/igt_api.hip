@@ -585,33 +585,35 @@ int forecast_impl(igt_handle* h, int32_t B, const T* ego_xyh, const T* opp, cons
     if (B < 0) return fail(IGT_E_INVALID, "B < 0");
     if (B == 0) return IGT_OK;
     if (!h->d_routes) return fail(IGT_E_STATE, "route table not set (igt_set_routes)");
-    if (h->p.n_obs != 1) return fail(IGT_E_INVALID, "the forecast entry covers two-vehicle scenes (n_obs = 1)");
+    if (h->p.n_obs < 1) return fail(IGT_E_INVALID, "the forecast entry needs at least one other vehicle (n_obs >= 1)");
     if (!ego_xyh || !opp || !opp_a || !opp_route || !obs_xy || !tv_sv) return fail(IGT_E_INVALID, "null buffer");
     const bool plans = plan_x && plan_u && has_plan;
     if (!plans && (plan_x || plan_u || has_plan)) return fail(IGT_E_INVALID, "plan_x, plan_u, has_plan go together");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     const int N = h->p.N;
-    const size_t n_e = (size_t)B * 3, n_o = (size_t)B * 4, n_px = (size_t)B * 7 * (N + 1), n_pu = (size_t)B * 2 * N;
-    const size_t n_out = (size_t)B * 2 * (N + 1), n_tv = (size_t)B * 2;
+    const size_t M1 = (size_t)h->p.n_obs;            // other vehicles per scene: every per-opponent array is [B, n_obs, ...]
+    const size_t n_e = (size_t)B * 3, n_o = (size_t)B * M1 * 4, n_px = (size_t)B * M1 * 7 * (N + 1), n_pu = (size_t)B * M1 * 2 * N;
+    const size_t n_out = (size_t)B * M1 * 2 * (N + 1), n_tv = (size_t)B * M1 * 2;
+    const size_t n_pairs = (size_t)B * M1;
     const T *de = ego_xyh, *dop = opp, *da = opp_a, *dpx = plan_x, *dpu = plan_u;
     const int32_t *dr = opp_route, *dhp = has_plan;
     T *dout = obs_xy, *dtv = tv_sv;
     if (mem == IGT_MEM_HOST) {
-        const size_t bytes = (n_e + n_o + B + (plans ? n_px + n_pu : 0) + n_out + n_tv) * sizeof(T) + (size_t)B * 8 + 16 * 256;
+        const size_t bytes = (n_e + n_o + n_pairs + (plans ? n_px + n_pu : 0) + n_out + n_tv) * sizeof(T) + n_pairs * 8 + 16 * 256;
         if (int rc = ensure_stage(h, bytes)) return rc;
         Arena ar{(char*)h->d_stage, 0};
-        T* a0 = ar.take<T>(n_e); T* a1 = ar.take<T>(n_o); T* a2 = ar.take<T>(B);
-        int32_t* a3 = ar.take<int32_t>(B); int32_t* a4 = ar.take<int32_t>(B);
+        T* a0 = ar.take<T>(n_e); T* a1 = ar.take<T>(n_o); T* a2 = ar.take<T>(n_pairs);
+        int32_t* a3 = ar.take<int32_t>(n_pairs); int32_t* a4 = ar.take<int32_t>(n_pairs);
         T* a5 = ar.take<T>(plans ? n_px : 1); T* a6 = ar.take<T>(plans ? n_pu : 1);
         dout = ar.take<T>(n_out); dtv = ar.take<T>(n_tv);
         HIPCHK(hipMemcpyAsync(a0, ego_xyh, n_e * sizeof(T), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(a1, opp, n_o * sizeof(T), hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(a2, opp_a, (size_t)B * sizeof(T), hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(a3, opp_route, (size_t)B * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(a2, opp_a, n_pairs * sizeof(T), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(a3, opp_route, n_pairs * 4, hipMemcpyHostToDevice, st));
         de = a0; dop = a1; da = a2; dr = a3;
         if (plans) {
-            HIPCHK(hipMemcpyAsync(a4, has_plan, (size_t)B * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(a4, has_plan, n_pairs * 4, hipMemcpyHostToDevice, st));
             HIPCHK(hipMemcpyAsync(a5, plan_x, n_px * sizeof(T), hipMemcpyHostToDevice, st));
             HIPCHK(hipMemcpyAsync(a6, plan_u, n_pu * sizeof(T), hipMemcpyHostToDevice, st));
             dhp = a4; dpx = a5; dpu = a6;

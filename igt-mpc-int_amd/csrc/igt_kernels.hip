@@ -475,8 +475,11 @@ __global__ __launch_bounds__(256) void forecast_kernel(KP P, int B, const double
                                                        const T* __restrict__ plan_x, const T* __restrict__ plan_u,
                                                        const int32_t* __restrict__ has_plan, T* __restrict__ obs_xy,
                                                        T* __restrict__ tv_sv) {
+    // one lane per (problem, other vehicle): pair = b n_obs + o -- the M - 1 obstacles of a scene (mpc.py:82-83 is written for any
+    // M) are forecast, shared and filtered independently of each other; `b` below indexes the per-pair arrays, `e` the ego's
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    const int e = P.n_obs > 1 ? b / P.n_obs : b;
     const int N = P.N;
     const T dt = (T)P.dt;
     int rid = opp_route[b];
@@ -514,12 +517,12 @@ __global__ __launch_bounds__(256) void forecast_kernel(KP P, int B, const double
         }
         sl = s; vl = v;
     }
-    tv_sv[(size_t)b * 2 + 0] = sl;
-    tv_sv[(size_t)b * 2 + 1] = vl;
+    tv_sv[(size_t)b * 2 + 0] = sl;           // last raw prediction of every other vehicle (mpc.py:263-276 raw_preds; the value
+    tv_sv[(size_t)b * 2 + 1] = vl;           // network's features read the one of a two-vehicle scene, mpc.py:330)
     // filter_preds (utils.py:365-388)
     T sh, ch;
-    sincos_t<T>(ego_xyh[(size_t)b * 3 + 2], &sh, &ch);
-    const T dot = (x0 - ego_xyh[(size_t)b * 3 + 0]) * ch + (y0 - ego_xyh[(size_t)b * 3 + 1]) * sh;
+    sincos_t<T>(ego_xyh[(size_t)e * 3 + 2], &sh, &ch);
+    const T dot = (x0 - ego_xyh[(size_t)e * 3 + 0]) * ch + (y0 - ego_xyh[(size_t)e * 3 + 1]) * sh;
     if (dot < 0)
         for (int k = 0; k <= N; ++k) { ox[k] = (T)-20; oy[k] = (T)-20; }
 }
@@ -842,7 +845,8 @@ template <typename T>
 hipError_t launch_forecast(const KP& P, int B, const double* routes, int n_routes, const T* ego_xyh, const T* opp,
                            const T* opp_a, const int32_t* opp_route, const T* plan_x, const T* plan_u,
                            const int32_t* has_plan, T* obs_xy, T* tv_sv, hipStream_t st) {
-    hipLaunchKernelGGL((forecast_kernel<T>), dim3((B + 255) / 256), dim3(256), 0, st, P, B, routes, n_routes, ego_xyh, opp,
+    const int pairs = B * (P.n_obs > 1 ? P.n_obs : 1);
+    hipLaunchKernelGGL((forecast_kernel<T>), dim3((pairs + 255) / 256), dim3(256), 0, st, P, pairs, routes, n_routes, ego_xyh, opp,
                        opp_a, opp_route, plan_x, plan_u, has_plan, obs_xy, tv_sv);
     return hipGetLastError();
 }

@@ -243,19 +243,24 @@ class BatchSolver:
 
     def forecast(self, ego_xyh, opp, opp_a, opp_route, plan_x=None, plan_u=None, has_plan=None, stream=None):
         """Opponent forecast + V2V sharing + filter_preds on the device (constant_acceleration_model.py:18-82,
-        utils.py:339-352, 365-388): -> (obs_xy[B,1,2,N+1], tv_sv[B,2])."""
+        utils.py:339-352, 365-388): -> (obs_xy[B,n_obs,2,N+1], tv_sv[B,2]).
+        Two-vehicle scenes (n_obs = 1): opp[B,4], opp_a[B], opp_route[B], plan_x[B,7,N+1], plan_u[B,2,N], has_plan[B].
+        M > 2 (mpc.py:82-83 takes any M): the same arrays with an n_obs axis behind B -- opp[B,n_obs,4], opp_a[B,n_obs], ... -- and
+        tv_sv[B,n_obs,2] (the last raw prediction of every other vehicle, mpc.py:263-276)."""
         if not self._routes_set:
             self.set_routes()
-        B, N = int(ego_xyh.shape[0]), self.N
+        B, N, M1 = int(ego_xyh.shape[0]), self.N, self.n_obs
         dt = self.np_dtype
+        tv_shape = (B, 2) if M1 == 1 else (B, M1, 2)
         if _is_torch(ego_xyh):
             import torch
-            obs = torch.empty((B, 1, 2, N + 1), dtype=ego_xyh.dtype, device=ego_xyh.device)
-            tv = torch.empty((B, 2), dtype=ego_xyh.dtype, device=ego_xyh.device)
+            obs = torch.empty((B, M1, 2, N + 1), dtype=ego_xyh.dtype, device=ego_xyh.device)
+            tv = torch.empty(tv_shape, dtype=ego_xyh.dtype, device=ego_xyh.device)
         else:
-            obs, tv = np.empty((B, 1, 2, N + 1), dt), np.empty((B, 2), dt)
+            obs, tv = np.empty((B, M1, 2, N + 1), dt), np.empty(tv_shape, dt)
+        ax = () if M1 == 1 else (M1,)
         arrs = [ego_xyh, opp, opp_a, opp_route, plan_x, plan_u, has_plan, obs, tv]
-        shapes = [(B, 3), (B, 4), (B,), (B,), (B, 7, N + 1), (B, 2, N), (B,), (B, 1, 2, N + 1), (B, 2)]
+        shapes = [(B, 3), (B, *ax, 4), (B, *ax), (B, *ax), (B, *ax, 7, N + 1), (B, *ax, 2, N), (B, *ax), (B, M1, 2, N + 1), tv_shape]
         dts = [dt, dt, dt, np.int32, dt, dt, np.int32, dt, dt]
         mode, ptrs, keep = self._prep(arrs, shapes, dts)
         self._check(self._fcast(self._h, B, *ptrs, mode, self._stream_ptr(stream, mode == L.IGT_MEM_DEVICE)))

@@ -247,11 +247,14 @@ int igt_set_routes(igt_handle* h, int32_t n_routes, const double* table);
  * ConstantAccelerationModel.predict (constant_acceleration_model.py:18-82), share_motion_forecasts
  * (utils.py:339-352: an opponent that solved last step shares its plan, shifted by one step and extended by
  * one predicted step; a = 0 if that step would exceed v = 5) and filter_preds (utils.py:365-388: an opponent
- * behind the ego is moved to (-20,-20)).  Two-vehicle scenes (n_obs = 1).
- *   ego_xyh  [B,3]  ego x, y, heading          opp [B,4]  opponent x, y, s, v (current)
- *   opp_a    [B]    opponent's last applied a  opp_route [B]  route id (row of the igt_set_routes table)
- *   plan_x [B,7,N+1], plan_u [B,2,N], has_plan [B] (int32, 0 = no shared plan)  -- all three may be NULL
- *   obs_xy [B,1,2,N+1] (out)   tv_sv [B,2] (out): (s, v) of the last forecast state (mpc.py:330) */
+ * behind the ego is moved to (-20,-20)).  Scenes of M = n_obs + 1 vehicles (mpc.py:82-83 is written for any M; the shipped
+ * fourwayint.yaml has M = 2): every per-opponent array carries an n_obs axis behind B, the opponents of a scene are forecast,
+ * shared and filtered independently (with n_obs = 1 the shapes are the two-vehicle ones, [B,4], [B], ...).
+ *   ego_xyh  [B,3]  ego x, y, heading                opp [B,n_obs,4]  opponent x, y, s, v (current)
+ *   opp_a    [B,n_obs]  opponent's last applied a    opp_route [B,n_obs]  route id (row of the igt_set_routes table)
+ *   plan_x [B,n_obs,7,N+1], plan_u [B,n_obs,2,N], has_plan [B,n_obs] (int32, 0 = no shared plan)  -- all three may be NULL
+ *   obs_xy [B,n_obs,2,N+1] (out)   tv_sv [B,n_obs,2] (out): (s, v) of every opponent's last forecast state (mpc.py:263-276; the
+ *   value network's features read the one of a two-vehicle scene, mpc.py:330) */
 int igt_forecast_batch_f32(igt_handle* h, int32_t B, const float* ego_xyh, const float* opp, const float* opp_a,
                            const int32_t* opp_route, const float* plan_x, const float* plan_u,
                            const int32_t* has_plan, float* obs_xy, float* tv_sv, int mem, void* stream);

@@ -188,6 +188,47 @@ def test_forecast_matches_oracle(golden_dir):
         assert 0.2 * B < n_filtered < 0.8 * B
 
 
+def test_forecast_of_three_and_four_vehicle_scenes_matches_oracle(golden_dir):
+    """Scenes of M > 2 vehicles (mpc.py:82-83 is written for any M): igt_forecast_batch_* with n_obs = 2 and 3 -- every
+    opponent of a scene forecast / shared / filtered on its own -- equals the two-vehicle entry called once per opponent, and the
+    route-by-route oracle; the result is what igt_solve_batch_* takes as obs_xy."""
+    import json
+    import igtmpc
+    from igtmpc import routes as R
+    with open(f'{golden_dir}/route_constants.json') as f:
+        C = json.load(f)
+    rng = np.random.default_rng(12)
+    B, N, dt = 96, 20, 0.1
+    ego = np.column_stack([rng.uniform(0, 50, B), rng.uniform(-20, 30, B), rng.uniform(-np.pi, np.pi, B)])
+    for M1 in (2, 3):
+        rid = rng.integers(0, 12, (B, M1))
+        s0, v0, a0 = rng.uniform(0, 50, (B, M1)), rng.uniform(0, 5.5, (B, M1)), rng.uniform(-2, 2, (B, M1))
+        xy = R.frenet2global(rid.ravel(), s0.ravel()).reshape(B, M1, 2)
+        opp = np.concatenate([xy, s0[..., None], v0[..., None]], axis=-1)
+        has_plan = (rng.random((B, M1)) < 0.5).astype(np.int32)
+        plan_x = rng.uniform(-5, 45, (B, M1, 7, N + 1))
+        plan_x[:, :, 5, :] = rng.uniform(3.5, 5.2, (B, M1, N + 1))
+        plan_u = rng.uniform(-1, 2, (B, M1, 2, N))
+        for dtype, npdt, tol in (('f64', np.float64, 1e-12), ('f32', np.float32, REL_TOL)):
+            c = lambda z: np.ascontiguousarray(z, dtype=npdt)
+            with igtmpc.BatchSolver(dtype=dtype, N=N, n_obs=M1) as s:
+                obs, tv = s.forecast(c(ego), c(opp), c(a0), rid.astype(np.int32), c(plan_x), c(plan_u), has_plan)
+            assert obs.shape == (B, M1, 2, N + 1) and tv.shape == (B, M1, 2)
+            with igtmpc.BatchSolver(dtype=dtype, N=N, n_obs=1) as s1:
+                for o in range(M1):
+                    o1, t1 = s1.forecast(c(ego), c(opp[:, o]), c(a0[:, o]), rid[:, o].astype(np.int32), c(plan_x[:, o]), c(plan_u[:, o]),
+                                         np.ascontiguousarray(has_plan[:, o]))
+                    assert np.array_equal(o1[:, 0], obs[:, o]) and np.array_equal(t1, tv[:, o])
+            cast = lambda z: np.asarray(z, dtype=npdt).astype(np.float64)
+            for b in range(0, B, 5):
+                for o in range(M1):
+                    st = [cast(opp[b, o, 0]), cast(opp[b, o, 1]), cast(opp[b, o, 2]), 0, 0, cast(opp[b, o, 3]), 0]
+                    e = cast(ego[b])
+                    ref, (sl, vl) = O.forecast_for_ego(R.ROUTES[rid[b, o]], C[R.ROUTES[rid[b, o]]], e[:2], e[2], st, float(cast(a0[b, o])), N, dt,
+                                                       cast(plan_x[b, o]) if has_plan[b, o] else None, cast(plan_u[b, o]) if has_plan[b, o] else None)
+                    assert rel_err(obs[b, o], ref).max() < tol and rel_err(tv[b, o], [sl, vl]).max() < tol
+
+
 def test_closed_loop_gt_mpc_mode(golden_dir):
     """evaluate.py --eval_mode gt_mpc counterpart: value network in the cost, (0,0) initial inputs, the first
     step's special forecast; runs with the shipped sc1 checkpoint (identity normalisation)."""
