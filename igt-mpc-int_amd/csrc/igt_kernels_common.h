@@ -102,6 +102,11 @@ __device__ __forceinline__ int small_div(int x, int d) {
 __device__ __forceinline__ bool steer_table_fits(const KP& P, int W, int cand) {
     return (cand == CAND_LATTICE || cand == CAND_RAMP_HOLD) && (P.G / W) * P.N <= STEER_TABLE_MAX_ENTRIES && !(P.dev & 4);
 }
+// UNIFORM: the caller's lanes all ask about the same scenario (a search / emit wave): wave-uniform results are moved to scalar
+// registers.  The queue builder asks per lane about DIFFERENT scenarios and must not (round 4: it did, so every lane of a builder
+// wave took the unit count of lane 0's scenario, and a scenario with more units than that had its last unit sorted with the
+// empty slices, at the very end of the queue -- 576 arc units of 30-60 us started after 100 us at B = 4096).
+template <bool UNIFORM = true>
 __device__ __forceinline__ UnitLayout unit_layout(const KP& P, int W, int cand, unsigned long long mask) {
     UnitLayout L;
     const bool slices = cand != CAND_TABLE && P.G * P.G == P.C && W * 64 == P.C && P.G % W == 0 && !(P.dev & 1);
@@ -118,7 +123,8 @@ __device__ __forceinline__ UnitLayout unit_layout(const KP& P, int W, int cand, 
     // 64 live candidates per unit, column by column from the centre outwards: a unit touches at most floor(63 / R) + 2 columns
     if (L.R > 0 && !(P.dev & 4194304) && (!table || (small_div(63, L.R) + 2) * P.N <= STEER_TABLE_MAX_ENTRIES)) {
         L.kind = 3; L.per = 0;
-        L.n_units = __builtin_amdgcn_readfirstlane((P.G * L.R + 63) >> 6);
+        L.n_units = (P.G * L.R + 63) >> 6;
+        if (UNIFORM) L.n_units = __builtin_amdgcn_readfirstlane(L.n_units);
         return L;
     }
     L.kind = 2;
@@ -127,8 +133,9 @@ __device__ __forceinline__ UnitLayout unit_layout(const KP& P, int W, int cand, 
     if (table) { const int cap = small_div(STEER_TABLE_MAX_ENTRIES, P.N); if (per > cap) per = cap; }
     // the float detour leaves these in vector registers although they are the same on every lane: back to scalars, or the
     // stride of the steering table is recomputed on the vector ALU at every control step
-    L.per = __builtin_amdgcn_readfirstlane(per);
-    L.n_units = __builtin_amdgcn_readfirstlane(L.R > 0 ? small_div(P.G + per - 1, per) : 0);
+    L.per = per;
+    L.n_units = L.R > 0 ? small_div(P.G + per - 1, per) : 0;
+    if (UNIFORM) { L.per = __builtin_amdgcn_readfirstlane(L.per); L.n_units = __builtin_amdgcn_readfirstlane(L.n_units); }
     return L;
 }
 // the steering columns (ranks, centre outwards) unit p touches: first and how many
@@ -185,8 +192,8 @@ __device__ __forceinline__ int unit_candidate(const KP& P, const UnitLayout& L, 
     else { unsigned long long m = L.mask; for (int t = 0; t < rank; ++t) m &= m - 1ull; row = __ffsll((long long)m) - 1; }
     return (row << lg) + j;
 }
-__device__ __forceinline__ int units_of_live_rows(const KP& P, int W, unsigned long long mask) {
-    return unit_layout(P, W, P.cand_mode, mask).n_units;
+__device__ __forceinline__ int units_of_live_rows(const KP& P, int W, unsigned long long mask) {      // per lane (queue builder)
+    return unit_layout<false>(P, W, P.cand_mode, mask).n_units;
 }
 
 // One workgroup per queue sorts its units into QC cost classes, most expensive first, keeping the scenario order
