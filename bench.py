@@ -474,12 +474,23 @@ def main():
             # ahead of its next one by the lane's stream alone
             u0_buf = [torch.empty((Bm, 2), dtype=td, device=f'cuda:{dev}') for _ in range(F)]
             gathered = [torch.empty((Bm * world, 2), dtype=td, device=f'cuda:{dev}') for _ in range(F)]
+        # the self-check behind the timed region reads every lane's outputs: a lane the overlapped steps (settle, warm-up, timed:
+        # all of them run F in flight) never wrote would show this sentinel.  Filled HERE, ahead of the settle phase, not between
+        # it and the warm-up steps: the first torch kernel of a process takes the host milliseconds to load, the device idles
+        # and clocks down meanwhile, and W = 5 warm-up steps (1 ms) do not bring the clock back -- the 20-step region behind them
+        # then runs 5 % slower (profiles/r04_idle_gap_before_warmup.txt; same box, alternating: 22.5 against 21.3 M solves/s)
+        for o in outs:
+            o['argmin'].fill_(-5)
+        if exchange:
+            for g in gathered:
+                g.fill_(-5.0)
+        torch.cuda.synchronize(dev)
         step_no = [0]
         drain_hint = os.environ.get('IGT_BENCH_NO_DRAIN_HINT') != '1'      # A/B switch (tools only)
 
         conc = [F] * F                    # what each handle was last told about the solves in flight
 
-        def step(in_flight_now=None):
+        def step(in_flight_now=None, ev=None):
             # in_flight_now: how many solves are in flight once this one is enqueued, when the caller knows (the timed loop does:
             # it enqueues exactly K steps and waits, so the last F - 1 steps see the pipeline drain) -- igt_set_concurrency is told,
             # as include/igtmpc.h asks of a caller that overlaps solves (below 3 in flight a search takes two waves per SIMD again
@@ -502,6 +513,8 @@ def main():
                 if exchange:
                     u0_buf[q].copy_(outs[q]['u'][:, :, 0])
                     dist.all_gather_into_tensor(gathered[q], u0_buf[q])
+                if ev is not None:
+                    ev.record()
 
         def fence():
             torch.cuda.synchronize(dev)
@@ -526,22 +539,22 @@ def main():
                 n_settle = int(ns.item())
             for _ in range(n_settle):
                 step()
-        # the self-check below reads every lane's outputs: a lane the overlapped steps never wrote would show this sentinel
-        torch.cuda.synchronize(dev)
-        for o in outs:
-            o['argmin'].fill_(-5)
-        if exchange:
-            for g in gathered:
-                g.fill_(-5.0)
         for _ in range(warmup):
             step()
         fence()
+        evs = None
+        if os.environ.get('IGT_BENCH_EVENTS') == '1':      # tools only: when each timed step completes (tools/region_events.py)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+            evs[steps].record()
         t0 = time.perf_counter()
         for i in range(steps):
-            step(in_flight_now=steps - i)      # the last F - 1 steps: fewer solves behind this one than lanes
+            step(in_flight_now=steps - i, ev=evs[i] if evs else None)      # the last F - 1 steps: fewer solves behind this one than lanes
         issued = time.perf_counter() - t0          # host time to enqueue the timed steps (close to `elapsed`: host-bound)
         fence()
         elapsed = time.perf_counter() - t0
+        if evs:
+            print(f'[events] {dtype} {cand_mode} F={F}: wall {elapsed * 1e3:.3f} ms, issued in {issued * 1e3:.3f}; steps complete at ' +
+                  ' '.join(f'{evs[steps].elapsed_time(e):.2f}' for e in evs[:steps]), file=sys.stderr, flush=True)
         if exchange:
             t = torch.tensor([elapsed], dtype=torch.float64, device=f'cuda:{dev}')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
