@@ -150,7 +150,7 @@ int validate(const igt_params& p, std::string& why) {
     }
     if (p.refine_iters < 0 || p.refine_iters > 4) { why = "refine_iters must be in [0, 4]"; return -1; }
     if (p.refine_iters > 0 && p.cand_mode != IGT_CAND_RAMP_HOLD && p.cand_mode != IGT_CAND_TRACK) { why = "refine_iters needs IGT_CAND_RAMP_HOLD or IGT_CAND_TRACK"; return -1; }
-    if (p.cand_mode == IGT_CAND_TRACK && (!(p.track_ke >= 0) || !(p.track_span >= 0) || !(p.track_beta_lim > 0) || !(p.track_beta_lim < 1.5) || !(p.track_env >= 0) || !(p.track_env < 1e6))) { why = "track_ke, track_span, track_env must be >= 0 (and finite) and 0 < track_beta_lim < 1.5"; return -1; }
+    if (p.cand_mode == IGT_CAND_TRACK && (!(p.track_ke >= 0) || !(p.track_span >= 0) || !(p.track_beta_lim > 0) || !(p.track_beta_lim < 1.5) || !(p.track_env >= 0) || !(p.track_env < 1e6) || !(p.track_vcap >= 0) || !(p.track_vcap < 1e6))) { why = "track_ke, track_span, track_env, track_vcap must be >= 0 (and finite) and 0 < track_beta_lim < 1.5"; return -1; }
     if (p.cost_mode != IGT_COST_PROGRESS && p.cost_mode != IGT_COST_VALUE_NET) { why = "unknown cost_mode"; return -1; }
     if (!(p.v_min <= p.v_max) || !(p.a_min <= p.a_max) || !(p.df_max >= 0)) { why = "inconsistent limits"; return -1; }
     if (!(p.feas_tol >= 0)) { why = "feas_tol must be >= 0"; return -1; }
@@ -177,12 +177,17 @@ igt::KP make_kp(const igt_params& p, int F) {
     k.w_u = p.w_u;
     k.tol = p.feas_tol;
     k.trk_ke = p.track_ke; k.trk_span = p.track_span; k.trk_blim = p.track_beta_lim;
-    // slope of the acceleration envelope (igt_device.h track_accel_target); products and one quotient only, so the
+    // slope of the acceleration envelope (igt_device.h track_accel_target_uncapped); products and one quotient only, so the
     // oracle's track_env_slope() gives the same bits
     // The envelope is the stationary point of  w_u a_k^2 - (s_N - s_0)  (mpc.py:362, 372).  The gt_mpc cost has no
     // progress term (mpc.py:367-370: the value network stands there), so with IGT_COST_VALUE_NET it is not applied.
     k.trk_env = (p.track_env > 0 && p.w_u > 0 && p.cost_mode == IGT_COST_PROGRESS)
                     ? p.track_env * p.dt * p.dt / (2 * p.w_u) : (double)INFINITY;
+    // speed cap of the acceleration targets (igt_device.h track_speed_cap): the speed it looks ahead to -- the box less a margin
+    // far above a float32 roll-out's rounding (oracle: TRACK_VCAP_MARGIN) --, +inf when off
+    k.trk_vmax = p.track_vcap > 0 ? p.v_max - 1e-4 : (double)INFINITY;
+    k.inv_dt = 1.0 / p.dt;
+    k.inv_rate_a = 1.0 / (p.dt * p.jerk_limit);
     // stage-offset polynomials: short form while h * (largest angular rate a candidate can reach) stays
     // small (igt_fast.h small_sincos2); v up to v_max + 2, |K| up to 0.25, sin(beta)/l_r <= 0.7/l_r
     const double vhi = std::fmax(std::fabs(p.v_min), std::fabs(p.v_max)) + 2.0;
@@ -361,11 +366,13 @@ int solve_impl(igt_handle* h, int32_t B, const T* x0, const T* u_prev, const T* 
         // double path, progress cost: the unit winners' horizon checkpoints for the emit in pieces (24 doubles per unit)
         const bool ck_ok = sizeof(T) == 8 && !value && !exact64 && p.N >= 8;
         const size_t ck_doubles = ck_ok ? (size_t)B * W * igt::CK_RECORD_DOUBLES : 0;
-        const size_t need = traj_doubles * 8 + 256 + (size_t)B * 16 + ck_doubles * 8 + 256 + (size_t)B * W * 12 + (size_t)B * 56 + 8192 + ckpt_bytes + (size_t)(B + 8) * Wk * 36 + 256 + n_rec * (2 * sizeof(T) + 16) +
+        // double path: the acceleration rows' travel sums [B, G] (accel_rows_kernel -> the tracking family's incumbent bound)
+        const size_t rows_doubles = sizeof(T) == 8 ? (size_t)B * (p.cand_mode == IGT_CAND_TABLE ? 1 : isqrt_exact(p.C)) : 0;
+        const size_t need = traj_doubles * 8 + 256 + (size_t)B * 16 + (ck_doubles + rows_doubles) * 8 + 256 + (size_t)B * W * 12 + (size_t)B * 56 + 8192 + ckpt_bytes + (size_t)(B + 8) * Wk * 36 + 256 + n_rec * (2 * sizeof(T) + 16) +
                             (value ? (size_t)B * igt::VN_H * sizeof(T) + (size_t)B * Wk * 8 + (size_t)B * 8 + n_rec * 4 + 512 : 0) + 20 * 256;
         if (int rc = ensure_work(h, need, st)) return rc;
         Arena wa{(char*)h->d_work, 0};
-        A.part_J = wa.take<double>((size_t)B * W + (sizeof(T) == 8 ? (size_t)2 * B : (size_t)B) + ck_doubles);  // double path: + [B] live-row masks + [B] incumbents + checkpoint records (igt_kernels_f64.hip); float path: + [B] incumbents
+        A.part_J = wa.take<double>((size_t)B * W + (sizeof(T) == 8 ? (size_t)2 * B : (size_t)B) + rows_doubles + ck_doubles);  // double path: + [B] live-row masks + [B] incumbents + [B G] row sums + checkpoint records (igt_kernels_f64.hip); float path: + [B] incumbents
         A.ck_ok = ck_ok;
         A.part_c = wa.take<int32_t>((size_t)B * W);
         d_cpar = wa.take<double>((size_t)B * 4);
@@ -719,7 +726,7 @@ int igt_params_default(igt_params* p) {
     p->w_u = 0.05;                                        /* mpc.py:362 */
     p->feas_tol = 1e-6;
     p->refine_iters = 0;
-    p->track_ke = 0.3; p->track_span = 0.1; p->track_beta_lim = 0.7; p->track_env = 1.0;
+    p->track_ke = 0.3; p->track_span = 0.1; p->track_beta_lim = 0.7; p->track_env = 1.0; p->track_vcap = 1.0;
     return IGT_OK;
 }
 

@@ -39,7 +39,8 @@ struct KP {  // kernel parameters (by value -> SGPRs)
     double dt, h, l_r, lr_ratio, v_min, v_max, a_min, a_max, df_max;
     double rate_a, rate_df, ey_lim, dmin2, w_u, tol;
     double trk_ke, trk_span, trk_blim;      // IGT_CAND_TRACK: lateral gain [1/m], span of the slip-angle offsets, |beta| limit
-    double trk_env;                         // IGT_CAND_TRACK: slope of the acceleration envelope (+inf = none), track_accel_target
+    double trk_env;                         // IGT_CAND_TRACK: slope of the acceleration envelope (+inf = none), track_accel_target_uncapped
+    double trk_vmax, inv_dt, inv_rate_a;    // IGT_CAND_TRACK: the speed the cap of the targets looks ahead to (+inf = no cap); 1 / dt, 1 / rate_a
 };
 
 enum { CAND_LATTICE = 0, CAND_TABLE = 1, CAND_RAMP_HOLD = 2, CAND_TRACK = 3 };
@@ -87,8 +88,44 @@ __device__ __forceinline__ double track_steer(const KP& P, double df_prev, doubl
 // more than E_k = dt^2 (N - k - 1/2) / (2 w_u), so the candidates' targets stay under that envelope -- a candidate
 // with a large offset ramps up at the jerk limit until it meets E_k and follows it down, which is the shape the
 // NLP's optimum has (tools/nlp_gap.py).  trk_env = track_env dt^2 / (2 w_u) (host, igt_api.hip), +inf when off.
-__device__ __forceinline__ double track_accel_target(const KP& P, int k, double base, double off) {
+// Speed cap of the targets (oracle: np_oracle.track_speed_cap).  The speed is v_{k+1} = v_k + dt a_k and the acceleration
+// comes down by at most r = dt jerk per step (mpc.py:301-304): from a_k the speed still gains dt S(a_k),
+// S(a) = (n + 1) a - r n (n + 1) / 2 with n = floor(a / r), before a reaches 0.  The largest a_k with v_k + dt S(a_k) <= v_max
+// (mpc.py:316-317) is, with D = (v_max - v_k) / dt:  n = floor((sqrt(1 + 8 D / r) - 1) / 2),  a = D / (n + 1) + r n / 2
+// (continuous in D, so a last-bit difference in the square root moves nothing; D < 0: a = D, one step back under the limit).
+// A candidate with a large offset therefore accelerates as hard as the limits allow and eases off so as to arrive at v_max
+// with a = 0 -- the NLP optimum's longitudinal shape (profiles/r04_nlp_gap.txt) -- where it used to fail the speed
+// box and leave the winner to a lower row.  D is clipped to 1000 (far from the cap, or no cap: trk_vmax = +inf).
+// n comes from a float square root and is then set right by the two float64 comparisons that define it (r n (n + 1) / 2 <= D <
+// r (n + 1) (n + 2) / 2); the quotient is rcp_nr's (1 ulp).
+__device__ __forceinline__ double track_speed_cap(const KP& P, double v) {
+    const double D = fmin((P.trk_vmax - v) * P.inv_dt, 1000.0);
+    const double Dp = fmax(D, 0.0);
+    const double hr = 0.5 * P.rate_a;
+    double n = (double)floorf((__builtin_sqrtf(1.0f + (float)(Dp * (8.0 / P.rate_a))) - 1.0f) * 0.5f);
+    n = fmax(n, 0.0);
+    if (hr * n * (n + 1.0) > Dp) n -= 1.0;
+    else if (hr * (n + 1.0) * (n + 2.0) <= Dp) n += 1.0;
+    return D < 0.0 ? D : fma(Dp, m64::rcp_nr(n + 1.0), hr * n);
+}
+__device__ __forceinline__ double track_accel_target_uncapped(const KP& P, int k, double base, double off) {
     return clampd(fmin(base + off, P.trk_env * ((double)(P.N - k) - 0.5)), P.a_min, P.a_max);
+}
+// a_k of the tracking family: one jerk-limited step (mpc.py:301-304) from a_{k-1} towards min(envelope target, speed cap).  The step towards
+// the UNCAPPED target is tried first: if it leaves the speed inside the cap -- S(a_try) <= D, the cap's own inequality, a
+// product and a floor -- the cap, being no smaller than a_try, would have changed nothing (a target above the cap is then out
+// of the step's reach anyway), and the wave skips the square root and the quotient unless one of its lanes needs them.
+// Which lanes take which branch decides nothing: both give the same a_k where both apply.
+__device__ __forceinline__ double track_accel_next(const KP& P, int k, double base, double off, double v, double a_prev) {
+    const double tu = track_accel_target_uncapped(P, k, base, off);
+    const double a_try = clampd(a_prev + clampd(tu - a_prev, -P.rate_a, P.rate_a), P.a_min, P.a_max);
+    const double D = fmin((P.trk_vmax - v) * P.inv_dt, 1000.0);
+    const double n = fmax(floor(a_try * P.inv_rate_a), 0.0);
+    const double S = fma(n + 1.0, a_try, -(0.5 * P.rate_a) * n * (n + 1.0));
+    if (__all(S <= D)) return a_try;
+    const double ta = clampd(fmin(tu, track_speed_cap(P, v)), P.a_min, P.a_max);
+    const double a_cap = clampd(a_prev + clampd(ta - a_prev, -P.rate_a, P.rate_a), P.a_min, P.a_max);
+    return S <= D ? a_try : a_cap;
 }
 
 // base sequence of the ramp-hold targets at step k
@@ -129,7 +166,8 @@ __device__ __forceinline__ void ctl_init(Ctl& c, const KP& P, int idx, double a_
 // advances to step k; returns violation bits for the input box / rate constraints
 template <typename T>
 __device__ __forceinline__ unsigned ctl_step(Ctl& c, const KP& P, int idx, int k, const double* __restrict__ table,
-                                             const T* __restrict__ ws, double a_prev, double df_prev, double ey, double ep) {
+                                             const T* __restrict__ ws, double a_prev, double df_prev, double ey, double ep,
+                                             double speed) {
     unsigned v = 0;
     if (P.cand_mode == CAND_TABLE) {
         const double a = table[((size_t)idx * 2 + 0) * P.N + k];
@@ -147,8 +185,7 @@ __device__ __forceinline__ unsigned ctl_step(Ctl& c, const KP& P, int idx, int k
     } else if (P.cand_mode == CAND_TRACK) {
         double ba, bdf;
         ramp_base<T>(ws, P.N, k, a_prev, df_prev, ba, bdf);
-        const double ta = track_accel_target(P, k, ba, c.da);
-        c.a = clampd(c.a + clampd(ta - c.a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
+        c.a = track_accel_next(P, k, ba, c.da, speed, c.a);
         c.df = track_steer(P, c.df, ey, ep, c.ddf);
     } else {
         c.a = clampd(c.a + c.da, P.a_min, P.a_max);
@@ -433,7 +470,7 @@ __device__ __forceinline__ void rollout_pass(const KP& P, const Scenario<T>& S, 
         for (int q = 0; q < NC; ++q) {
             double cur[7];
             stp.get(st[q], cur);
-            bk[q].viol |= ctl_step<T>(ctl[q], P, cidx[q], k, table, S.ws, S.a_prev, S.df_prev, cur[3], cur[4]);
+            bk[q].viol |= ctl_step<T>(ctl[q], P, cidx[q], k, table, S.ws, S.a_prev, S.df_prev, cur[3], cur[4], cur[5]);
             sink.ctrl(q, k, ctl[q].a, ctl[q].df);
             // control effort first, then the tracking terms of state k (mpc.py:361-364)
             bk[q].J = bk[q].J + P.w_u * (ctl[q].a * ctl[q].a + ctl[q].df * ctl[q].df);

@@ -386,7 +386,7 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
                                             Sink& sink, double& Jout, unsigned& vout, double& sN, double& vN,
                                             const double* __restrict__ stab = nullptr, int stab_stride = 0,
                                             const unsigned long long* inc = nullptr, double* ck = nullptr, int seg_k0 = 0,
-                                            int seg_k1 = 0) {
+                                            int seg_k1 = 0, const double* __restrict__ rem_rows = nullptr) {
     constexpr bool BOUND = CAND == CAND_TRACK && BOOK && UNIFORM && EARLY_EXIT;
     // search on units of live acceleration rows (igt_kernels_f64.hip accel_rows_kernel; launch-time bit 30 of KP::dev): the speed
     // box and the terminal set read the row's (a, v) recurrence alone and were judged there, with these statements -- every lane
@@ -442,8 +442,12 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
             } else if (CAND == CAND_RAMP_HOLD || CAND == CAND_TRACK) {
                 double ba, bdf;
                 ramp_base<double>(S.ws, P.N, k, S.a_prev, S.df_prev, ba, bdf);
-                const double ta = CAND == CAND_TRACK ? track_accel_target(P, k, ba, da) : clampd(ba + da, P.a_min, P.a_max);
-                a = clampd(a + clampd(ta - a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
+                if (CAND == CAND_TRACK) {
+                    a = track_accel_next(P, k, ba, da, v, a);
+                } else {
+                    const double ta = clampd(ba + da, P.a_min, P.a_max);
+                    a = clampd(a + clampd(ta - a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
+                }
                 if (CAND == CAND_RAMP_HOLD) df = steer_next<CAND>(P, S, k, ddf, df);
             } else {
                 a = table[((size_t)cidx * 2 + 0) * P.N + k];
@@ -464,15 +468,18 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
     if (BOUND && inc) {
         seg_scale = progress_slack(P, S) * P.dt;
         if (seg_scale > 0.0) {
-            double a2 = S.a_prev, v2 = S.x0[5];
-            for (int k = 0; k < P.N; ++k) {
-                double ba, bdf;
-                ramp_base<double>(S.ws, P.N, k, S.a_prev, S.df_prev, ba, bdf);
-                const double ta = track_accel_target(P, k, ba, da);
-                a2 = clampd(a2 + clampd(ta - a2, -P.rate_a, P.rate_a), P.a_min, P.a_max);
-                const double vn = fma(fp.dt, a2, v2);
-                rem += fmax(fabs(v2), fabs(vn));
-                v2 = vn;
+            if (rem_rows) {          // the row's sum as accel_rows_kernel left it (the statements of the loop in the other branch)
+                rem = rem_rows[cidx / P.G];
+            } else {
+                double a2 = S.a_prev, v2 = S.x0[5];
+                for (int k = 0; k < P.N; ++k) {
+                    double ba, bdf;
+                    ramp_base<double>(S.ws, P.N, k, S.a_prev, S.df_prev, ba, bdf);
+                    a2 = track_accel_next(P, k, ba, da, v2, a2);
+                    const double vn = fma(fp.dt, a2, v2);
+                    rem += fmax(fabs(v2), fabs(vn));
+                    v2 = vn;
+                }
             }
             rem *= seg_scale * (1.0 + 1e-12);
         } else {
@@ -501,8 +508,7 @@ __device__ __forceinline__ void rollout_one(const KP& P, const Scenario<double>&
         } else if (CAND == CAND_TRACK) {
             double ba, bdf;
             ramp_base<double>(S.ws, P.N, k, S.a_prev, S.df_prev, ba, bdf);
-            const double ta = track_accel_target(P, k, ba, da);
-            a = clampd(a + clampd(ta - a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
+            a = track_accel_next(P, k, ba, da, v, a);
             df = track_steer(P, df, ey, ep, ddf, &trk_sb, &trk_cb, &trk_followed);
         } else {
             const double an = table[((size_t)cidx * 2 + 0) * P.N + k];

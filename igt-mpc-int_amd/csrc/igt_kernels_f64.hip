@@ -179,7 +179,7 @@ template <int CAND>
 __global__ __launch_bounds__(256) void accel_rows_kernel(KP P, int B, const double* __restrict__ x0,
                                                          const double* __restrict__ u_prev, const uint32_t* __restrict__ flags,
                                                          const double* __restrict__ cinf, Centre<double> cpar,
-                                                         unsigned long long* __restrict__ row_mask) {
+                                                         unsigned long long* __restrict__ row_mask, double* __restrict__ row_rem) {
     const int lane = threadIdx.x & 63, lg = __ffs(P.G) - 1;                  // G is a power of two (igt_api.hip)
     const int per_wave = 64 >> lg;                                           // scenarios per wave
     const int wave = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
@@ -193,22 +193,40 @@ __global__ __launch_bounds__(256) void accel_rows_kernel(KP P, int B, const doub
         double da;
         if (CAND == CAND_LATTICE) da = -P.rate_a + (2 * P.rate_a) * (double)i / (double)(P.G - 1);
         else da = c0 + cand_m(i, P.G, P.refine_it == 0) * c2;
-        double a = a_prev, v = x0[(size_t)b * 7 + 5], g = -1.0e300;
+        double a = a_prev, v = x0[(size_t)b * 7 + 5], g = -1.0e300, travel = 0.0;
         unsigned viol = 0;
+        bool twin = CAND == CAND_TRACK && i > 0;          // so far the row's accelerations are those of the row below it
         for (int k = 0; k < P.N; ++k) {
             if (CAND == CAND_LATTICE) {
                 a = clampd(a + da, P.a_min, P.a_max);
             } else {
                 double ba, bdf;
                 ramp_base<double>(ws, P.N, k, a_prev, df_prev, ba, bdf);
-                const double ta = CAND == CAND_TRACK ? track_accel_target(P, k, ba, da) : clampd(ba + da, P.a_min, P.a_max);
-                a = clampd(a + clampd(ta - a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
+                if (CAND == CAND_TRACK) {
+                    a = track_accel_next(P, k, ba, da, v, a);
+                } else {
+                    const double ta = clampd(ba + da, P.a_min, P.a_max);
+                    a = clampd(a + clampd(ta - a, -P.rate_a, P.rate_a), P.a_min, P.a_max);
+                }
+            }
+            if (CAND == CAND_TRACK) {          // lane - 1: row i - 1 of the same scenario.  Every lane takes part in the exchange
+                const double below = __shfl_up(a, 1, 64);      // whatever its own flag says: the lane above it reads what it holds
+                twin = twin && (a == below);
             }
             g = fmax(g, fmax(P.v_min - v, v - P.v_max));                             // mpc.py:316-317 (k < N)
             if (k == P.N - 1) viol |= terminal_viol(P, v, a, cinf);                  // mpc.py:177-180
-            v = fma(P.dt, a, v);
+            const double vn = fma(P.dt, a, v);
+            travel += fmax(fabs(v), fabs(vn));           // sum_k max(|v_k|, |v_k+1|): what the incumbent bound lets the row still gain
+            v = vn;
         }
-        live = !(g > P.tol) && viol == 0;
+        // (igt_fast64.h BOUND reads it instead of rolling the recurrence ahead once more at the start of every unit: with the speed
+        // cap in the targets that preamble had grown to a third of a pruned unit's instructions)
+        if (CAND == CAND_TRACK && row_rem) row_rem[(size_t)b * P.G + i] = travel;
+        // A tracking row whose N accelerations are, bit for bit, those of the row below it (both ride the speed cap, the envelope
+        // or a box limit) rolls the same G candidates again: same trajectories, same costs, and the arg-min's tie rule gives them
+        // to the lower index anyway -- the row is left out.  (With the speed cap the rows above the one that just reaches v_max
+        // are all such twins; before it they failed the speed box and were left out for that.)
+        live = !(g > P.tol) && viol == 0 && !twin;
     }
     const unsigned long long m = __ballot(live);
     if (b < B && i == 0) {
@@ -234,8 +252,12 @@ __device__ __forceinline__ unsigned long long* incumbents_of(const KP& P, int B,
 constexpr int DEV_CKPT = 1 << 29;
 constexpr int DEV_NO_SEG_EMIT = 16777216;   // IGT_DEV_FLAGS: emit re-rolls the winner in one piece (A/B runs, bitwise test)
 constexpr int CK_RECORD = (f64::CK_PARTS - 1) * f64::CK_FIELDS;
+// behind the incumbents: the rows' travel sums [B G] (accel_rows_kernel, tracking family), then the checkpoint records
+__device__ __forceinline__ double* row_rems_of(const KP& P, int B, int W, double* part_J) {
+    return part_J + (size_t)B * W + 2 * (size_t)B;
+}
 __device__ __forceinline__ double* checkpoints_of(const KP& P, int B, int W, double* part_J) {
-    return (P.dev & DEV_CKPT) ? part_J + (size_t)B * W + 2 * (size_t)B : nullptr;
+    return (P.dev & DEV_CKPT) ? part_J + (size_t)B * W + 2 * (size_t)B + (size_t)B * P.G : nullptr;
 }
 // queue items in unit-rank-major order when the tracking family's incumbents are in use and no order table was built
 __device__ __forceinline__ bool rank_major_items(const KP& P, int cand, bool value) {
@@ -265,9 +287,10 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
                                               int32_t* __restrict__ rec_b, int2* __restrict__ unit_seg,
                                               const unsigned long long* __restrict__ row_mask = nullptr,
                                               double* __restrict__ traj = nullptr, unsigned long long* inc_all = nullptr,
-                                              double* __restrict__ ck_all = nullptr) {
+                                              double* __restrict__ ck_all = nullptr, const double* __restrict__ rem_all = nullptr) {
     const int lane = threadIdx.x & 63;
     unsigned long long* inc = inc_all ? inc_all + b : nullptr;
+    const double* rem_rows = (inc_all && rem_all) ? rem_all + (size_t)b * P.G : nullptr;
     const UnitLayout L = unit_layout(P, W, CAND, row_mask ? row_mask[b] : ~0ull);
     if (p >= L.n_units) {             // the scenario's live rows fit fewer units: this slice holds nothing
         if (lane == 0) {
@@ -321,9 +344,9 @@ __device__ __forceinline__ void search_unit64(const KP& P, int W, int b, int p, 
                                                                                         stab + col * 3, nj * 3, nullptr, ck_lds);
         __syncthreads();                                  // the next unit of this wave rewrites the table
     } else if (far) {
-        f64::rollout_one<CAND, HI, true, true, NullSink, true, false, NRK, false, SM>(P, S, c, table, cinf, sink, J, viol, sN, vN, nullptr, 0, inc, ck_lds);
+        f64::rollout_one<CAND, HI, true, true, NullSink, true, false, NRK, false, SM>(P, S, c, table, cinf, sink, J, viol, sN, vN, nullptr, 0, inc, ck_lds, 0, 0, rem_rows);
     } else {
-        f64::rollout_one<CAND, HI, true, true, NullSink, true, false, NRK, true, SM>(P, S, c, table, cinf, sink, J, viol, sN, vN, nullptr, 0, inc, ck_lds);
+        f64::rollout_one<CAND, HI, true, true, NullSink, true, false, NRK, true, SM>(P, S, c, table, cinf, sink, J, viol, sN, vN, nullptr, 0, inc, ck_lds, 0, 0, rem_rows);
     }
     }
     if (VALUE) {   // terminal value network (mpc.py:369): append the feasible candidates for value_mfma_f64_kernel; the
@@ -375,7 +398,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
         search_unit64<CAND, HI, VALUE, NRK>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN,
                                        rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg, live_rows_of(P, B, W, part_J), nullptr,
-                                       incumbents_of<CAND, VALUE>(P, B, W, part_J), checkpoints_of(P, B, W, part_J));
+                                       incumbents_of<CAND, VALUE>(P, B, W, part_J), checkpoints_of(P, B, W, part_J), row_rems_of(P, B, W, part_J));
     }, rank_major_items(P, CAND, VALUE));
 }
 template <int CAND, bool HI, bool VALUE, int NRK>      // held to 256 registers for the tracking family (see search_fast_kernel_o2w)
@@ -383,7 +406,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     search_waves(P, B, W, queues, work_counter, order, order_stride, [&](int b, int p) {
         search_unit64<CAND, HI, VALUE, NRK>(P, W, b, p, x0, u_prev, kparams, flags, obs, table, cinf, cpar, part_J, part_c, rec_sN,
                                        rec_vN, rec_J, rec_viol, rec_count, rec_b, unit_seg, live_rows_of(P, B, W, part_J), nullptr,
-                                       incumbents_of<CAND, VALUE>(P, B, W, part_J), checkpoints_of(P, B, W, part_J));
+                                       incumbents_of<CAND, VALUE>(P, B, W, part_J), checkpoints_of(P, B, W, part_J), row_rems_of(P, B, W, part_J));
     }, rank_major_items(P, CAND, VALUE));
 }
 // small batches (captures_trajectories): the same search, every unit also leaves its 64 trajectories in `traj`
@@ -819,7 +842,7 @@ static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A
             rows = reinterpret_cast<const unsigned long long*>(A.part_J + (size_t)B * W);
             const int per_block = 4 * (64 / P.G);                      // scenarios per 256-thread block
             hipLaunchKernelGGL((accel_rows_kernel<CAND>), dim3((B + per_block - 1) / per_block), dim3(256), 0, st, P, B, A.x0, A.u_prev,
-                               A.flags, A.cinf, A.centre(), const_cast<unsigned long long*>(rows));
+                               A.flags, A.cinf, A.centre(), const_cast<unsigned long long*>(rows), A.part_J + (size_t)B * W + 2 * (size_t)B);
             Pr.dev |= DEV_LIVE_ROWS;
         }
     }
@@ -894,7 +917,7 @@ static hipError_t launch_emit64(const KP& P, int B, int W, const SolveArgs<doubl
     if (emits_in_pieces(P, A)) {
         const int S = seg_scenarios_per_block(P);
         const size_t lds = (size_t)S * seg_doubles_per_scenario(P.N) * 8;
-        double* ck = A.part_J + (size_t)B * W + 2 * (size_t)B;
+        double* ck = A.part_J + (size_t)B * W + 2 * (size_t)B + (size_t)B * P.G;
         if (NRK4 == 4 && P.n_rk4 == 4)
             hipLaunchKernelGGL((emit_seg_f64_kernel<CAND, HI, NRK4>), dim3((B + S - 1) / S), dim3(SEG_THREADS), lds, st, P, B, W, S, A.x0, A.u_prev,
                                A.kparams, A.flags, A.obs, A.table, A.cinf, A.centre(), A.part_J, A.part_c, ck, A.cost_out, A.argmin_out,

@@ -53,7 +53,7 @@ struct SolveArgs {   // all device pointers
     unsigned* live_idx;             // double path: entries left for the network after value_prune_kernel
     unsigned long long* row_mask;   // double path: [B] live acceleration rows of the generated families (accel_rows_kernel)
     double* traj;                   // double path, small batches: [B C/64][9][N+1][64] kept by the search pass (null: none)
-    bool ck_ok;                     // double path: part_J is followed by [B] masks, [B] incumbents and [B C/64][24] checkpoint records
+    bool ck_ok;                     // double path: part_J is followed by [B] masks, [B] incumbents, [B G] row travel sums and [B C/64][24] checkpoint records
 };
 constexpr int CK_RECORD_DOUBLES = 24;   // igt_fast64.h (CK_PARTS - 1) * CK_FIELDS
 

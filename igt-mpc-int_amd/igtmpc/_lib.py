@@ -25,7 +25,7 @@ class igt_params(C.Structure):
                 ('ey_lim', C.c_double), ('d_min', C.c_double), ('w_u', C.c_double), ('feas_tol', C.c_double),
                 ('refine_iters', C.c_int32), ('reserved', C.c_int32),
                 ('track_ke', C.c_double), ('track_span', C.c_double), ('track_beta_lim', C.c_double),
-                ('track_env', C.c_double)]
+                ('track_env', C.c_double), ('track_vcap', C.c_double)]
 
 
 # every symbol include/igtmpc.h declares: name -> (restype, argtypes)

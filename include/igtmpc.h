@@ -116,6 +116,10 @@ typedef struct igt_params {
     double track_env;        /* IGT_CAND_TRACK: scale of the acceleration envelope E_k; 0 = no envelope     (1.0)
                                 Applied with IGT_COST_PROGRESS only: E_k is derived from the progress term
                                 (mpc.py:372), which the IGT_COST_VALUE_NET cost does not have (mpc.py:367-370) */
+    double track_vcap;       /* IGT_CAND_TRACK: > 0: the acceleration targets also stay under the speed cap -- the largest
+                                a_k from which a jerk-limited ramp to a = 0 (mpc.py:301-304) still keeps v <= v_max
+                                (mpc.py:316-317): a candidate with a large offset accelerates at the limits and arrives
+                                at v_max with a = 0 instead of failing the speed box; 0 = off                  (1.0)  */
 } igt_params;
 
 /* Fills *p with the reference's numbers: N=20, dt=0.1, n_rk4=4, C=256, n_obs=1,
@@ -308,7 +312,8 @@ int igt_set_concurrency(igt_handle* h, int32_t solves_in_flight);
 
 /* Workspace (owned by the handle, grown on the first solve of a batch size, never shrunk; growth synchronises the stream and is
  * refused under stream capture with IGT_E_STATE).  Per scenario, C = 256: 48 B of slice partials, 16 B of live-row masks and
- * incumbent keys (float64; float32: 8 B), 768 B of horizon checkpoints of the unit winners (float64, progress cost, N >= 8),
+ * incumbent keys (float64; float32: 8 B), 128 B of the acceleration rows' travel sums (float64), 768 B of horizon checkpoints of
+ * the unit winners (float64, progress cost, N >= 8),
  * 288 B of queue order / counters; value-network cost: + 36 B per candidate (the list of feasible candidates).  Small float64
  * batches (no more 64-candidate units than the device has SIMDs: B <= 256 at C = 256) keep every candidate's trajectory for
  * the emit pass: 9 (N + 1) 64 doubles per unit = 97 KB per unit at N = 20, i.e. up to 99 MB per handle at B C / 64 = 1024. */

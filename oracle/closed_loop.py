@@ -93,7 +93,7 @@ def augment_prev_sol(x_sol_prev, u_sol_prev, kp, P):
 
 
 def run_episode(x_init, routes, P, cinf, M_sim=30, cand_mode='lattice', C=256, refine_iters=0, warm_start=True,
-                u_init=None, eval_mode='mpc', net=None, track_env=1.0, a_min_policy=A_MIN_POLICY, constant_speed=False):
+                u_init=None, eval_mode='mpc', net=None, track_env=1.0, track_vcap=1.0, a_min_policy=A_MIN_POLICY, constant_speed=False):
     """x_init[M,7] (planner state order), routes = (route of agent 0, route of agent 1).
     eval_mode 'gt_mpc' needs net = dict(layers, Wn, mu_f, sigma_t, mu_t) (np_oracle.terminal_value).
     track_env: scale of the tracking family's acceleration envelope (the driver under test picks it from the horizon).
@@ -148,7 +148,7 @@ def run_episode(x_init, routes, P, cinf, M_sim=30, cand_mode='lattice', C=256, r
                           enc=np.array([[code[i], code[j]]], dtype=np.float64))
             if cand_mode in ('ramp_hold', 'track'):
                 r = O.solve_batch_refined(*args, C=C, refine_iters=refine_iters, u_ws=u_ws, cand=cand_mode,
-                                          track=dict(env=track_env), **kw)[-1]
+                                          track=dict(env=track_env, vcap=track_vcap), **kw)[-1]
             else:
                 r = O.solve_batch(*args, C=C, **kw)
             if r['status'][0] == 0:                                                        # evaluate.py:484-510

@@ -545,14 +545,16 @@ def test_closed_loop_matches_oracle_loop(cand_mode):
     P = O.Params(N=20)
     ev = dict(fallback=0, stop=0, share=0, share_retry=0, warm=0)
     # With the terminal set, a feasible plan ends inside C_inf, i.e. at most 0.009 m/s above v = 5 one step later: the
-    # shared-plan retry (utils.py:348) is all but unreachable.  The fast episode therefore runs without it.
+    # shared-plan retry (utils.py:348) is all but unreachable.  The fast episode therefore runs without it -- and, in the tracking
+    # family, without the speed cap of the targets (igt_params.track_vcap), under which no plan ends above v = 5 either.
     for sel, terminal in (([0, 1, 3], True), ([2], False)):
+        vcap = 1.0 if terminal else 0.0
         got = run_closed_loop(N=20, T_sim=3.0, dtype='f64', cand_mode=cand_mode, init=(x[sel], [pairs[e] for e in sel]),
-                              terminal_set=terminal)
+                              terminal_set=terminal, limits=dict(track_vcap=vcap) if cand_mode == 'track' else None)
         cinf = cinf_halfplanes() if terminal else (None, None)
         for q, e in enumerate(sel):
             ref = CL.run_episode(x[e], pairs[e], P, cinf, M_sim=30, cand_mode=cand_mode,
-                                 track_env=got['track_env'] if cand_mode == 'track' else 1.0)
+                                 track_env=got['track_env'] if cand_mode == 'track' else 1.0, track_vcap=vcap)
             for k in ev:
                 ev[k] += ref['events'][k]
             assert rel_err(got['x_data'][q], ref['x_data']).max() < 1e-9, (e, pairs[e])

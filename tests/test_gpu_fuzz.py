@@ -46,6 +46,8 @@ def _draw(seed):
         lim['w_u'] = 0.3
     if cfg['cand'] == 'track' and rng.random() < 0.5:
         lim['track_env'] = float(rng.choice([0.0, 0.5]))
+    if cfg['cand'] == 'track' and rng.random() < 0.3:
+        lim['track_vcap'] = 0.0
     cfg['limits'] = lim
     return cfg
 
@@ -77,6 +79,8 @@ def _draw_ext(seed):
         lim['d_min'] = float(rng.choice([4.0, 7.0]))
     if cfg['cand'] == 'track' and rng.random() < 0.5:
         lim['track_env'] = float(rng.choice([0.0, 0.5]))
+    if cfg['cand'] == 'track' and rng.random() < 0.3:
+        lim['track_vcap'] = 0.0
     cfg['limits'] = lim
     return cfg
 
@@ -163,7 +167,8 @@ def _run(seed, golden_dir, dtype):
             s.set_cinf(*cinf)
         if net:
             s.set_value_net(**net)
-        tk = dict(ke=s.params.track_ke, span=s.params.track_span, blim=s.params.track_beta_lim, env=s.params.track_env)
+        tk = dict(ke=s.params.track_ke, span=s.params.track_span, blim=s.params.track_beta_lim, env=s.params.track_env,
+                  vcap=s.params.track_vcap)
         got = s.solve(b['x0'], u_prev, b['kparams'], flags, obs, *extra, u_ws=u_ws)
         n_all = min(B, 4)
         allc = s.rollout_all(b['x0'][:n_all], u_prev[:n_all], b['kparams'][:n_all], flags[:n_all], obs[:n_all],

@@ -961,6 +961,61 @@ def test_tracking_steering_feedback_over_its_whole_range(igt):
     assert rel_err(all_['X'][fin], ref['X'][fin]).max() <= 1e-9
 
 
+@pytest.mark.parametrize('dtype', ['f64', 'f32'])
+def test_tracking_speed_cap_matches_oracle(igt, dtype):
+    """igt_params.track_vcap (default on): the acceleration targets stay under the largest a_k from which a jerk-limited ramp
+    still keeps v <= v_max (igt_device.h track_speed_cap; oracle np_oracle.track_speed_cap).  Scenarios that start near the
+    speed limit (v0 = 3.6 .. 4.9 m/s) so that the top rows meet the cap: every candidate's controls and the solve agree with the
+    oracle with the cap on and off, capped candidates stay inside the speed box, and the cap never makes an answer worse."""
+    B = 128
+    npdt = np.float64 if dtype == 'f64' else np.float32
+    b = _batch(B, npdt)
+    rng = np.random.default_rng(77)
+    x0 = np.array(b['x0'], dtype=npdt)
+    x0[:, 5] = rng.uniform(3.6, 4.9, B).astype(npdt)
+    u_prev = np.array(b['u_prev'], dtype=npdt)
+    u_prev[:, 0] = rng.uniform(-0.2, 1.2, B).astype(npdt)
+    f = lambda a: np.asarray(a, dtype=np.float64)
+    args = (x0, u_prev, b['kparams'], b['flags'], b['obs_xy'])
+    res = {}
+    for vcap in (1.0, 0.0):
+        with igt.BatchSolver(dtype=dtype, cand_mode='track', track_vcap=vcap) as s:
+            P = oracle_params(s)
+            assert s.params.track_vcap == vcap
+            s.set_cinf(*_cinf())
+            all_ = s.rollout_all(*[a[:32] for a in args])
+            got = s.solve(*args)
+        ref = O.solve_batch_refined(f(x0), f(u_prev), f(b['kparams']), b['flags'], f(b['obs_xy']), *_cinf(), P, cand='track',
+                                    track=dict(vcap=vcap))[0]
+        kp = f(b['kparams'])[:, None, :]
+        bp = O.breakpoint_distance(O.apply_flags(f(x0), b['flags'])[:, None, :], ref['U'], kp, P)
+        clear = bp[:32] > (1e-9 if dtype == 'f64' else 2e-5)
+        tolU, tolx = (1e-12, 1e-9) if dtype == 'f64' else (2e-5, 1e-4)
+        assert rel_err(all_['U'][clear], ref['U'][:32][clear]).max() <= tolU
+        eps = 1e-9 if dtype == 'f64' else 2e-5
+        ok = ~ambiguous_mask(ref, P, eps, eps, eps, bp)
+        assert ok.mean() > 0.6, ok.mean()
+        assert (got['argmin'][ok] == ref['argmin'][ok]).all() and (got['status'][ok] == ref['status'][ok]).all()
+        sol = ok & (ref['status'] == 0)
+        assert sol.sum() > 30 and rel_err(got['x'][sol], ref['x'][sol]).max() <= tolx
+        res[vcap] = (got, ref)
+    got1, ref1 = res[1.0]
+    got0, ref0 = res[0.0]
+    # the highest acceleration row under the cap: inside the speed box over the whole horizon, at v_max - margin at the end
+    a_top1, a_top0 = ref1['U'][:, 15 * 16 + 8, 0, :], ref0['U'][:, 15 * 16 + 8, 0, :]
+    v1 = f(x0)[:, 5:6] + np.cumsum(P.dt * a_top1, axis=1)
+    v0 = f(x0)[:, 5:6] + np.cumsum(P.dt * a_top0, axis=1)
+    # (where the initial (v, a) still allows it: from v0 = 4.9 with a = 1.2 no jerk-limited ramp stays under the limit)
+    ctrl = O.track_speed_cap(f(x0)[:, 5], P) >= f(u_prev)[:, 0] - P.dt * P.jerk
+    assert ctrl.mean() > 0.5 and v1[ctrl].max() <= P.v_max - O.TRACK_VCAP_MARGIN + 1e-9
+    assert (v0.max(axis=1) > P.v_max + 0.05).mean() > 0.8
+    both = (ref1['status'] == 0) & (ref0['status'] == 0)
+    assert both.sum() > 40 and (ref1['cost'][both] <= ref0['cost'][both] + 1e-12).all()
+    assert (ref1['cost'][both] < ref0['cost'][both] - 1e-3).mean() > 0.3          # ... and often better
+    gb = (got1['status'] == 0) & (got0['status'] == 0)
+    assert (got1['cost'][gb] < got0['cost'][gb] - 1e-3).mean() > 0.3
+
+
 @pytest.mark.parametrize('env', [0.0, 0.5])
 def test_tracking_envelope_scale_matches_oracle(igt, env):
     """igt_params.track_env: 0 switches the acceleration envelope off (constant targets), any other scale moves the

@@ -150,8 +150,8 @@ def test_c_abi_exports_every_declared_symbol():
     assert (p.N, p.n_rk4, p.C, p.n_obs) == (20, 4, 256, 1)
     assert (p.v_min, p.v_max, p.a_min, p.a_max, p.df_max) == (0, 5, -4, 3, 1)
     assert (p.jerk_limit, p.steer_rate_limit, p.ey_lim, p.d_min, p.w_u) == (0.9, 0.7, 0.2, 5.6, 0.05)
-    assert abs(p.l_r - 2.235) < 1e-15 and ct.sizeof(L.igt_params) == 24 + 14 * 8 + 8 + 4 * 8 and p.refine_iters == 0
-    assert (p.track_ke, p.track_span, p.track_beta_lim, p.track_env) == (0.3, 0.1, 0.7, 1.0)
+    assert abs(p.l_r - 2.235) < 1e-15 and ct.sizeof(L.igt_params) == 24 + 14 * 8 + 8 + 5 * 8 and p.refine_iters == 0
+    assert (p.track_ke, p.track_span, p.track_beta_lim, p.track_env, p.track_vcap) == (0.3, 0.1, 0.7, 1.0, 1.0)
     # struct layout agrees with the header's field order
     fields = re.search(r'typedef struct igt_params \{(.*?)\} igt_params;', hdr, re.S).group(1)
     names = re.findall(r'\b(?:int32_t|double)\s+([^;]+);', fields)

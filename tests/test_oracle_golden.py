@@ -181,6 +181,46 @@ def test_tracking_envelope_is_the_stationary_acceleration_of_the_longitudinal_pr
     assert np.allclose(U0[15 * 16 + 8, 0], np.minimum(ramp, O.cand_m(15, 16, True) * P.N * P.dt * P.jerk))
 
 
+def test_tracking_speed_cap_arrives_at_v_max_with_zero_acceleration():
+    """np_oracle.track_speed_cap: the largest a_k from which a jerk-limited ramp down (mpc.py:301-304) keeps v <= v_max
+    (mpc.py:316-317).  (1) the closed form inverts S(a) = (n + 1) a - r n (n + 1) / 2, n = floor(a / r); (2) rolled forward at
+    the cap the speed climbs to v_max and never passes it, the acceleration comes down by at most r per step and ends at 0;
+    (3) the tracking candidate with the largest offset follows it -- it survives the speed box where, without the cap, it
+    fails it -- and with vcap off the family is the one of before."""
+    P = O.Params()
+    r = P.dt * P.jerk
+    v = np.linspace(P.v_max - 3.0, P.v_max + 0.05, 4001)
+    a = O.track_speed_cap(v, P)
+    vm = P.v_max - O.TRACK_VCAP_MARGIN
+    D = (vm - v) / P.dt
+    n = np.floor(np.maximum(a, 0.0) / r + 1e-12)
+    S = np.where(D < 0, a, (n + 1) * a - r * n * (n + 1) / 2)
+    assert np.abs(S - D).max() < 1e-12 and np.all(np.diff(a) < 0)
+    assert np.isinf(O.track_speed_cap(v, P, on=False)).all()
+    for v0, a0 in ((3.0, 0.0), (4.2, 0.9), (4.9, 0.3)):
+        vv, aa, hist = v0, a0, []
+        for k in range(60):
+            aa = float(np.clip(aa + np.clip(min(P.a_max, O.track_speed_cap(vv, P)) - aa, -r, r), P.a_min, P.a_max))
+            vv = vv + P.dt * aa
+            hist.append((vv, aa))
+        hv, ha = np.array(hist).T
+        assert hv.max() <= vm + 1e-12 and abs(hv[-1] - vm) < 1e-9 and abs(ha[-1]) < 1e-9, (v0, a0, hv.max(), ha[-1])
+        assert np.all(np.abs(np.diff(ha)) <= r + 1e-12)
+    x0 = np.array([[0.0, 0.0, 5.0, 0.0, 0.0, 4.2, 0.0]])
+    kp = np.array([[np.inf, np.inf, 0.0]])
+    u_prev = np.array([[0.5, 0.0]])
+    c, sp = O.track_first_params(u_prev, P)
+    U1 = O.candidates_track(x0, u_prev, kp, c, sp, True, P)[0]
+    U0 = O.candidates_track(x0, u_prev, kp, c, sp, True, P, vcap=False)[0]
+    top = 15 * 16 + 8
+    v1 = x0[0, 5] + np.concatenate([[0.0], np.cumsum(P.dt * U1[top, 0])])
+    v0_ = x0[0, 5] + np.concatenate([[0.0], np.cumsum(P.dt * U0[top, 0])])
+    assert v1.max() <= vm + 1e-12 and v1[-1] > vm - 1e-6 and v0_.max() > P.v_max + 0.1
+    assert abs(U1[top, 0, -1]) < 1e-6
+    low = 0 * 16 + 8                                       # a braking row never meets the cap: unchanged
+    assert np.array_equal(U1[low], U0[low])
+
+
 def test_all_eight_shipped_value_networks_reproduce_the_reference_forward(golden_dir):
     """igtmpc/data/value_nets.npz (weights of V_GT_sc1..8, exported as data) through the oracle's forward pass gives the
     outputs the reference's own model.py produced on the golden inputs (tests/golden/make_golden.py, V_sc{n}); the two

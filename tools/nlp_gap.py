@@ -33,6 +33,7 @@ def main():
     rh = O.solve_batch_refined(*args, refine_iters=2)
     fam['ramp-hold'], fam['ramp-hold + 2 refinements'] = rh[0], rh[-1]
     fam['tracking, no envelope'] = O.solve_batch_refined(*args, cand='track', track=dict(env=0.0))[0]
+    fam['tracking, no speed cap (rounds 2-3)'] = O.solve_batch_refined(*args, cand='track', track=dict(vcap=0.0))[0]
     tr = O.solve_batch_refined(*args, refine_iters=2, cand='track')
     fam['tracking (default)'], fam['tracking + 2 refinements'] = tr[0], tr[-1]
     J = np.stack([np.where(f['status'] == 0, f['cost'], np.inf) for f in fam.values()])      # [families, n]
@@ -50,7 +51,7 @@ def main():
     for (name, f), Jf in zip(fam.items(), J):
         m = ok & np.isfinite(Jf)
         g = Jf[m] - J_opt[m]
-        print(f'{name:28s}: solves {np.isfinite(Jf).mean() * 100:5.1f} %   gap mean {g.mean():.4f}  median {np.median(g):.4f}  '
+        print(f'{name:36s}: solves {np.isfinite(Jf).mean() * 100:5.1f} %   gap mean {g.mean():.4f}  median {np.median(g):.4f}  '
               f'p90 {np.quantile(g, 0.9):.4f}  max {g.max():.4f}   ({m.sum()} scenarios)')
 
 
