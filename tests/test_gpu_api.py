@@ -339,22 +339,27 @@ def test_nan_inputs_and_determinism():
         assert np.array_equal(ob[k][keep], o1[k][keep], equal_nan=True)
 
 # ----------------------------------------------------------------------------- stream capture
-@pytest.mark.parametrize('B', [512, 4096])
-def test_solve_is_capturable_in_a_graph(B):
+@pytest.mark.parametrize('B,dtype,cand', [(512, 'f32', 'lattice'), (4096, 'f32', 'lattice'), (4096, 'f64', 'lattice'),
+                                          (2048, 'f64', 'track')])
+def test_solve_is_capturable_in_a_graph(B, dtype, cand):
     """The solve is a fixed sequence of stream operations (kernels, one memset node) once its workspace exists: captured
     in a graph and replayed on new inputs written into the same buffers, it gives what the eager call gives.
-    (B = 512: queue builder + checkpointed emit; B = 4096: queue builder + plain emit.)"""
+    (B = 512: queue builder + checkpointed emit; B = 4096: queue builder + plain emit; f64: acceleration rows, queue builder,
+    search with the incumbents of the tracking family, emit in pieces.  The graph is replayed three times, on alternating
+    inputs, with eager solves of another size on the same handle in between: every launch must leave the handle's counters
+    and incumbents as it found them.)"""
     import torch
     import igtmpc
     from igtmpc.scenarios import make_batch
     from igtmpc.cinf import cinf_halfplanes
+    npdt = np.float32 if dtype == 'f32' else np.float64
 
-    def dev(b):
-        return [torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda()
+    def dev(b, n=None):
+        return [torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a)[:n].contiguous().cuda()
                 for a in (b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy'])]
 
-    b1, b2 = make_batch(B, dtype=np.float32, seed=1), make_batch(B, dtype=np.float32, seed=2)
-    with igtmpc.BatchSolver(dtype='f32') as s:
+    b1, b2 = make_batch(B, dtype=npdt, seed=1), make_batch(B, dtype=npdt, seed=2)
+    with igtmpc.BatchSolver(dtype=dtype, cand_mode=cand) as s:
         s.set_cinf(*cinf_halfplanes())
         bufs = dev(b1)
         side = torch.cuda.Stream()
@@ -364,15 +369,18 @@ def test_solve_is_capturable_in_a_graph(B):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=side):
             s.solve(*bufs, out=out)
-        for dst, src in zip(bufs, dev(b2)):
-            dst.copy_(src)
-        g.replay()
-        torch.cuda.synchronize()
-        replayed = {k: v.clone() for k, v in out.items()}
-        eager = s.solve(*dev(b2))
-        torch.cuda.synchronize()
-    for k in ('x', 'u', 'cost', 'argmin', 'status'):
-        assert torch.equal(replayed[k].nan_to_num(), eager[k].nan_to_num()), k
+        for rnd, src_batch in enumerate((b2, b1, b2)):
+            for dst, src in zip(bufs, dev(src_batch)):
+                dst.copy_(src)
+            g.replay()
+            torch.cuda.synchronize()
+            replayed = {k: v.clone() for k, v in out.items()}
+            smaller = s.solve(*dev(src_batch, B - 300))      # (a smaller batch: the workspace does not grow)
+            eager = s.solve(*dev(src_batch))
+            torch.cuda.synchronize()
+            for k in ('x', 'u', 'cost', 'argmin', 'status'):
+                assert torch.equal(replayed[k].nan_to_num(), eager[k].nan_to_num()), (rnd, k)
+                assert torch.equal(smaller[k].nan_to_num(), eager[k][:B - 300].nan_to_num()), (rnd, k)
     assert (eager['status'] == 0).float().mean() > 0.5
 
 
