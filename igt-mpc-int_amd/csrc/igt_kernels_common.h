@@ -200,51 +200,77 @@ __device__ __forceinline__ int units_of_live_rows(const KP& P, int W, unsigned l
 // inside a class (a stable counting sort, so the order is a function of the inputs alone).
 // order[q][k] = (scenario ordinal in the queue) * 256 + slice.
 constexpr int QC = 8, QB_THREADS = 1024, QB_TRIPS = 2;     // up to 2048 units per queue (B <= 8192 at W = 2)
-template <typename T>
-__global__ __launch_bounds__(QB_THREADS) void build_queues_kernel(KP P, int B, int W, const T* __restrict__ x0,
-                                                                  const T* __restrict__ kparams,
-                                                                  unsigned* __restrict__ order, int stride,
-                                                                  unsigned* __restrict__ work_counter,
-                                                                  const unsigned long long* __restrict__ row_mask = nullptr) {
+// The body for one queue q, run by one workgroup of QB_THREADS_ threads in QB_TRIPS_ trips (QB_THREADS_ * QB_TRIPS_ = 2048): the
+// stand-alone kernel below takes 1024 x 2; the float64 prelude (igt_kernels_f64.hip accel_rows_kernel, whose first eight
+// workgroups sort the queues while the others roll the acceleration rows) 256 x 8.
+// row_mask: the scenarios' live acceleration rows when they are known at this point (a slice beyond the live rows' units is
+// a hole and sorts last); null: not known -- such slices are sorted as if they held candidates and the search skips them
+// when it gets there.  by_rows: the tracking family's units are cut along the acceleration axis (unit-rank-major order).
+template <typename T, int QB_THREADS_, int QB_TRIPS_>
+__device__ __forceinline__ void build_queue(const KP& P, int B, int W, int q, const T* __restrict__ x0,
+                                            const T* __restrict__ kparams, unsigned* __restrict__ order, int stride,
+                                            unsigned* __restrict__ work_counter,
+                                            const unsigned long long* __restrict__ row_mask, bool by_rows) {
+    constexpr int QB_THREADS = QB_THREADS_, QB_TRIPS = QB_TRIPS_;
     __shared__ int cnt[QB_TRIPS][QB_THREADS / 64][QC];   // [trip][wave][class] counts, then exclusive offsets
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) work_counter[q * 64] = 0u;             // this queue's unit counter (saves the memset node)
     const int n_scen = (B + 7) / 8, n = n_scen * W;
-    int cls[QB_TRIPS], rank[QB_TRIPS];
-#pragma unroll
-    for (int t = 0; t < QB_TRIPS; ++t) {
-        const int i = t * QB_THREADS + tid;
-        int c = -1;
-        if (i < n) {
-            const int j = i / W, p = i - j * W, b = queue_scenario(q, j);
-            c = QC - 1;                                  // a hole of the last block of 8: sorts last, skipped by the search
-            if (b < B && (!row_mask || p < units_of_live_rows(P, W, row_mask[b]))) {      // a slice beyond the live rows' units: a hole too
-                const float s0 = (float)x0[(size_t)b * 7 + 2], v0 = (float)x0[(size_t)b * 7 + 5];
-                const float b0 = (float)kparams[(size_t)b * 3 + 0], b1 = (float)kparams[(size_t)b * 3 + 1], kv = (float)kparams[(size_t)b * 3 + 2];
-                const float reach = s0 + 1.5f * fmaxf(v0, 1.0f) * (float)(P.N * P.dt);
-                const bool arc = kv != 0.0f && reach >= b0 && s0 <= b1;
-                // share of the horizon rolled: the central slice lives to the end; the outer ones leave the lane the sooner the
-                // faster the vehicle is -- except where the route bends within reach: there the outer steering columns are the
-                // ones that can follow it, and every slice may live long; and the tracking family's units (acceleration rows,
-                // steering by feedback) all do (91 % of their wave-steps are executed)
-                const float frac = (p == 0 || arc || P.cand_mode == CAND_TRACK) ? 0.95f : fminf(fmaxf(1.05f - 0.15f * v0, 0.4f), 0.95f);
-                const float cost = frac * (arc ? 1.9f : 1.0f);                                        // 0.4 .. 1.8
+    // 1. the classes, one thread per scenario (its W units share what is read of it): cls_s[j W + p]
+    __shared__ unsigned char cls_s[QB_THREADS * QB_TRIPS];
+#pragma unroll 2
+    for (int j = tid; j < n_scen; j += QB_THREADS) {
+        const int b = queue_scenario(q, j);
+        int nu = 0;                                      // a hole of the last block of 8: sorts last, skipped by the search
+        float frac_out = 0.95f, weight = 1.0f;
+        if (b < B) {
+            nu = row_mask ? units_of_live_rows(P, W, row_mask[b]) : W;
+            const float s0 = (float)x0[(size_t)b * 7 + 2], v0 = (float)x0[(size_t)b * 7 + 5];
+            const float b0 = (float)kparams[(size_t)b * 3 + 0], b1 = (float)kparams[(size_t)b * 3 + 1], kv = (float)kparams[(size_t)b * 3 + 2];
+            const float reach = s0 + 1.5f * fmaxf(v0, 1.0f) * (float)(P.N * P.dt);
+            const bool arc = kv != 0.0f && reach >= b0 && s0 <= b1;
+            // share of the horizon rolled: the central slice lives to the end; the outer ones leave the lane the sooner the
+            // faster the vehicle is -- except where the route bends within reach: there the outer steering columns are the
+            // ones that can follow it, and every slice may live long; and the tracking family's units (acceleration rows,
+            // steering by feedback) all do (91 % of their wave-steps are executed)
+            frac_out = (arc || P.cand_mode == CAND_TRACK) ? 0.95f : fminf(fmaxf(1.05f - 0.15f * v0, 0.4f), 0.95f);
+            weight = arc ? 1.9f : 1.0f;
+        }
+        // float64 tracking units (cut along the acceleration axis, highest rows in unit 0): unit-rank-major -- every scenario's
+        // unit 0 before any unit 1 -- so that a later unit of a scenario starts when the earlier ones have left their best cost
+        // as its incumbent (igt_fast64.h BOUND)
+        const bool by_rank = P.cand_mode == CAND_TRACK && (by_rows || (sizeof(T) == 4 && (P.dev & (1 << 30)))) && !(P.dev & 262144);
+        for (int p = 0; p < W; ++p) {
+            int c = QC - 1;
+            if (p < nu) {
+                const float cost = (p == 0 ? 0.95f : frac_out) * weight;                              // 0.4 .. 1.8
                 c = (int)((1.85f - cost) * ((float)QC / 1.5f));
                 c = c < 0 ? 0 : (c > QC - 1 ? QC - 1 : c);
-                // float64 tracking units (row_mask given: cut along the acceleration axis, highest rows in unit 0): unit-rank-major
-                // -- every scenario's unit 0 before any unit 1 -- so that a later unit of a scenario starts when the earlier ones
-                // have left their best cost as its incumbent (igt_fast64.h BOUND)
-                if (P.cand_mode == CAND_TRACK && (row_mask || (sizeof(T) == 4 && (P.dev & (1 << 30)))) && !(P.dev & 262144))
-                    c = W <= QC ? p : (p * QC) / W;
+                if (by_rank) c = W <= QC ? p : (p * QC) / W;
             }
+            cls_s[j * W + p] = (unsigned char)c;
         }
-        cls[t] = c; rank[t] = 0;
+    }
+    __syncthreads();
+    // 2. an item's class and its rank among its wave's items of that class: in registers over two trips; over more (the
+    // prelude's 256 threads) in LDS, the trips not unrolled
+    constexpr bool IN_LDS = QB_TRIPS > 2;
+    constexpr int UNROLL = IN_LDS ? 1 : QB_TRIPS;
+    __shared__ unsigned short cls_rank[IN_LDS ? QB_THREADS * QB_TRIPS : 1];
+    int cls[IN_LDS ? 1 : QB_TRIPS], rank[IN_LDS ? 1 : QB_TRIPS];
+#pragma unroll UNROLL
+    for (int t = 0; t < QB_TRIPS; ++t) {
+        const int i = t * QB_THREADS + tid;
+        const int c = i < n ? (int)cls_s[i] : -1;
+        int r = 0;
 #pragma unroll
         for (int cc = 0; cc < QC; ++cc) {
             const unsigned long long m = __ballot(c == cc);
             if (lane == 0) cnt[t][wv][cc] = __popcll(m);
-            if (c == cc) rank[t] = __popcll(m & ((1ull << lane) - 1ull));
+            if (c == cc) r = __popcll(m & ((1ull << lane) - 1ull));
         }
+        if constexpr (IN_LDS) cls_rank[t * QB_THREADS + tid] = (unsigned short)(((c < 0 ? 15 : c) << 8) | r);
+        else { cls[t] = c; rank[t] = r; }
     }
     __syncthreads();
     __shared__ int total[QC];
@@ -255,14 +281,26 @@ __global__ __launch_bounds__(QB_THREADS) void build_queues_kernel(KP P, int B, i
         total[tid] = run;
     }
     __syncthreads();
-#pragma unroll
+#pragma unroll UNROLL
     for (int t = 0; t < QB_TRIPS; ++t) {
-        if (cls[t] < 0) continue;
-        int off = cnt[t][wv][cls[t]] + rank[t];
-        for (int cc = 0; cc < cls[t]; ++cc) off += total[cc];      // the more expensive classes come first
+        int c, r;
+        if constexpr (IN_LDS) { const int cr = cls_rank[t * QB_THREADS + tid]; c = (cr >> 8) == 15 ? -1 : (cr >> 8); r = cr & 255; }
+        else { c = cls[t]; r = rank[t]; }
+        if (c < 0) continue;
+        int off = cnt[t][wv][c] + r;
+        for (int cc = 0; cc < c; ++cc) off += total[cc];      // the more expensive classes come first
         const int i = t * QB_THREADS + tid, j = i / W, p = i - j * W;
         order[(size_t)q * stride + off] = (unsigned)j * 256u + (unsigned)p;
     }
+}
+template <typename T>
+__global__ __launch_bounds__(QB_THREADS) void build_queues_kernel(KP P, int B, int W, const T* __restrict__ x0,
+                                                                  const T* __restrict__ kparams,
+                                                                  unsigned* __restrict__ order, int stride,
+                                                                  unsigned* __restrict__ work_counter,
+                                                                  const unsigned long long* __restrict__ row_mask = nullptr) {
+    build_queue<T, QB_THREADS, QB_TRIPS>(P, B, W, (int)blockIdx.x, x0, kparams, order, stride, work_counter, row_mask,
+                                         row_mask != nullptr);
 }
 
 // Persistent waves, one per workgroup.  Replacing a retired single-unit workgroup costs tens of microseconds of idle

@@ -175,14 +175,32 @@ __global__ __launch_bounds__(256) void rollout_all_kernel(KP P, int B, const T* 
 // one lane per (scenario, acceleration row), 64 / G scenarios per wave: the row's (a_k, v_k) recurrence with the two verdicts that
 // read nothing else -- the statements of rollout_one (igt_fast64.h), in its order; what load_scenario reads of the scenario for
 // them (a_prev, v_0, the warm start, the refinement centre) is read per lane here
-template <int CAND>
-__global__ __launch_bounds__(256) void accel_rows_kernel(KP P, int B, const double* __restrict__ x0,
+//
+// QUEUES (batches whose search queues are sorted, B <= 4096 at 256 candidates): the first eight workgroups of the same launch
+// sort one queue each (build_queue, eight trips of 256 threads) while the others roll the rows -- one launch instead of two
+// (the queue builder's own launch cost 7 us of a 236 us solve).  The two kinds of workgroup do not talk to each other: the
+// queues are sorted without the masks, so a slice beyond a scenario's live rows' units is sorted like any other slice of
+// its class and the search wave that takes it finds it empty and moves on.  (Sorting them last needs the masks first: as
+// a second launch that is the 7 us; inside this one it was built with tickets and a device-scope fence per workgroup and
+// cost 20 us, profiles/r04_ab_fused_prelude.txt.)
+constexpr int ROWS_THREADS = 256, ROWS_QB_TRIPS = QB_THREADS * QB_TRIPS / ROWS_THREADS;
+template <int CAND, bool QUEUES>
+__global__ __launch_bounds__(ROWS_THREADS) void accel_rows_kernel(KP P, int B, const double* __restrict__ x0,
                                                          const double* __restrict__ u_prev, const uint32_t* __restrict__ flags,
                                                          const double* __restrict__ cinf, Centre<double> cpar,
-                                                         unsigned long long* __restrict__ row_mask, double* __restrict__ row_rem) {
+                                                         unsigned long long* __restrict__ row_mask, double* __restrict__ row_rem,
+                                                         int W, const double* __restrict__ kparams, unsigned* __restrict__ order,
+                                                         int order_stride, unsigned* __restrict__ work_counter) {
+    if constexpr (QUEUES) {
+        if (blockIdx.x < 8) {
+            build_queue<double, ROWS_THREADS, ROWS_QB_TRIPS>(P, B, W, (int)blockIdx.x, x0, kparams, order, order_stride,
+                                                             work_counter, nullptr, true);
+            return;
+        }
+    }
     const int lane = threadIdx.x & 63, lg = __ffs(P.G) - 1;                  // G is a power of two (igt_api.hip)
     const int per_wave = 64 >> lg;                                           // scenarios per wave
-    const int wave = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int wave = ((int)blockIdx.x - (QUEUES ? 8 : 0)) * (ROWS_THREADS / 64) + (int)(threadIdx.x >> 6);
     const int b = wave * per_wave + (lane >> lg), i = lane & (P.G - 1);
     bool live = false;
     if (b < B) {
@@ -837,16 +855,25 @@ static hipError_t launch_search64(const KP& P, int B, const SolveArgs<double>& A
     KP Pr = P;
     if (!VALUE && emits_in_pieces(P, A)) Pr.dev |= DEV_CKPT;
     const unsigned long long* rows = nullptr;
+    bool queues_built = false;
     if constexpr (CAND != CAND_TABLE) {
         if (packs_live_rows(P, B, A)) {
             rows = reinterpret_cast<const unsigned long long*>(A.part_J + (size_t)B * W);
-            const int per_block = 4 * (64 / P.G);                      // scenarios per 256-thread block
-            hipLaunchKernelGGL((accel_rows_kernel<CAND>), dim3((B + per_block - 1) / per_block), dim3(256), 0, st, P, B, A.x0, A.u_prev,
-                               A.flags, A.cinf, A.centre(), const_cast<unsigned long long*>(rows), A.part_J + (size_t)B * W + 2 * (size_t)B);
+            const int per_block = (ROWS_THREADS / 64) * (64 / P.G);    // scenarios per workgroup
+            const int n_groups = (B + per_block - 1) / per_block;
+            // small batches: the same launch sorts the queues (longest units first)
+            queues_built = search_builds_queues(P, B, A) && !(P.dev & 33554432);
+#define IGT_LAUNCH_ROWS(QUEUES_)                                                                                              \
+            hipLaunchKernelGGL((accel_rows_kernel<CAND, QUEUES_>), dim3(n_groups + (QUEUES_ ? 8 : 0)), dim3(ROWS_THREADS), 0, st, P, \
+                               B, A.x0, A.u_prev, A.flags, A.cinf, A.centre(), const_cast<unsigned long long*>(rows),        \
+                               A.part_J + (size_t)B * W + 2 * (size_t)B, W, A.kparams, A.queue_order, order_stride,           \
+                               A.work_counter)
+            if (queues_built) { IGT_LAUNCH_ROWS(true); order = A.queue_order; } else IGT_LAUNCH_ROWS(false);
+#undef IGT_LAUNCH_ROWS
             Pr.dev |= DEV_LIVE_ROWS;
         }
     }
-    if (search_builds_queues(P, B, A)) {                     // small batches: longest units first
+    if (!queues_built && search_builds_queues(P, B, A)) {    // small batches: longest units first
         hipLaunchKernelGGL(build_queues_kernel<double>, dim3(8), dim3(QB_THREADS), 0, st, P, B, W, A.x0, A.kparams,
                            A.queue_order, order_stride, A.work_counter, rows);
         order = A.queue_order;

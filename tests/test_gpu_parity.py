@@ -559,12 +559,13 @@ def test_production_kernel_switches_change_nothing(igt, dtype, cand, monkeypatch
     """The A/B switches of the production kernels (IGT_DEV_FLAGS; VERDICT r2: "untested surface") only change HOW the work
     is laid out -- candidate slices in index order (1), no early exit (2), no steering table (4), no longest-first queues
     (16), no stealing between the XCDs' queues (512), tracking units cut along the steering axis (262144), units made of all
-    acceleration rows instead of the live ones (2097152) -- never the
+    acceleration rows instead of the live ones (2097152), the queues sorted by a launch of their own that knows the live rows
+    instead of by the first workgroups of the acceleration-rows kernel (33554432) -- never the
     answer: every one of them gives the default solve bit for bit, on a batch small enough to take the queue builder."""
     npdt = np.float64 if dtype == 'f64' else np.float32
     b = _batch(1536, npdt)
     outs = {}
-    for flag in (0, 1, 2, 4, 16, 512, 262144, 2097152, 8388608, 16777216, 1 | 2 | 4 | 16 | 512, 4 | 2097152):
+    for flag in (0, 1, 2, 4, 16, 512, 262144, 2097152, 8388608, 16777216, 33554432, 1 | 2 | 4 | 16 | 512, 4 | 2097152):
         monkeypatch.setenv('IGT_DEV_FLAGS', str(flag))
         with igt.BatchSolver(dtype=dtype, cand_mode=cand) as s:
             s.set_cinf(*_cinf())
@@ -615,7 +616,8 @@ def test_units_of_live_acceleration_rows_change_nothing(igt, golden_dir, cand, N
         outs = []
         net = dict(layers=_nets(golden_dir)[1], Wn=np.eye(6) + 0.05 * rng.normal(size=(6, 6)), mu_f=np.zeros(6), sigma_t=2.0, mu_t=0.3)
         # live rows, 64 per unit (tracking: + the incumbent bound); all rows; live rows in whole columns; (tracking:) no incumbent bound
-        for flag in ('0', '2097152', '4194304') + (('8388608',) if cand == 'track' else ()):
+        # ... ; the queue builder as a launch of its own (where the batch has one)
+        for flag in ('0', '2097152', '4194304') + (('8388608',) if cand == 'track' else ()) + (('33554432',) if B <= 4500 else ()):
             monkeypatch.setenv('IGT_DEV_FLAGS', flag)
             with igt.BatchSolver(N=N, C=C, dtype='f64', cand_mode=cand, cost_mode=cost_mode,     # (tracking at N = 40: with a refinement
                                  refine_iters=1 if (cand == 'ramp_hold' or (cand == 'track' and N == 40)) else 0) as s:   # pass -- the incumbents restart)
