@@ -326,6 +326,29 @@ __device__ __forceinline__ unsigned terminal_viol(const KP& P, double v, double 
     return (P.F > 0 && worst > P.tol) ? (unsigned)VIOL_TERMINAL : 0u;
 }
 
+// the same test with the facets fetched eight at a time -- 24 consecutive doubles, three 64-byte scalar loads in flight, where
+// the loop above waits for one facet's three numbers per trip (74 facets: 74 scalar-load latencies, 3 us of accel_rows_kernel's
+// 8 us).  The same expressions in the same order: the same bits.
+__device__ __forceinline__ unsigned terminal_viol_x8(const KP& P, double v, double a, const double* __restrict__ cinf) {
+    double worst = -1e300;
+    int m = 0;
+    for (; m + 8 <= P.F; m += 8) {
+        double f[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) f[i] = cinf[m * 3 + i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double t = f[i * 3 + 0] * v + f[i * 3 + 1] * a - f[i * 3 + 2];
+            worst = fmax(worst, t);
+        }
+    }
+    for (; m < P.F; ++m) {
+        const double t = cinf[m * 3 + 0] * v + cinf[m * 3 + 1] * a - cinf[m * 3 + 2];
+        worst = fmax(worst, t);
+    }
+    return (P.F > 0 && worst > P.tol) ? (unsigned)VIOL_TERMINAL : 0u;
+}
+
 // the same test for two candidates at once, four facets per trip: the facets arrive by scalar loads whose latency
 // (not the 6 flops per facet) is what one wave pays, so they are issued in batches and shared by both candidates
 __device__ __forceinline__ void terminal_viol2(const KP& P, const double (&v)[2], const double (&a)[2],

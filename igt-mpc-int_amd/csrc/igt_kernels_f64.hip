@@ -232,7 +232,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void accel_rows_kernel(KP P, int B, c
                 twin = twin && (a == below);
             }
             g = fmax(g, fmax(P.v_min - v, v - P.v_max));                             // mpc.py:316-317 (k < N)
-            if (k == P.N - 1) viol |= terminal_viol(P, v, a, cinf);                  // mpc.py:177-180
+            if (k == P.N - 1) viol |= terminal_viol_x8(P, v, a, cinf);               // mpc.py:177-180
             const double vn = fma(P.dt, a, v);
             travel += fmax(fabs(v), fabs(vn));           // sum_k max(|v_k|, |v_k+1|): what the incumbent bound lets the row still gain
             v = vn;
