@@ -7,7 +7,7 @@ from collections import defaultdict
 def family(name):
     if 'emit_seg_f64' in name:          # the float64 emit in pieces (round 4) reports as the float64 emit
         return 'emit_f64'
-    for key in ('search_f64', 'emit_f64', 'search_fast', 'emit_fast', 'emit_seg', 'build_queues', 'value_mfma', 'value_bound', 'value_select', 'value_compact', 'value_kernel',
+    for key in ('search_f64', 'emit_f64', 'search_fast', 'emit_fast', 'emit_seg', 'build_queues', 'accel_rows', 'value_mfma', 'value_bound', 'value_select', 'value_compact', 'value_kernel',
                 'keys_to_partials', 'refine_targets', 'rollout_all', 'forecast', 'search_kernel', 'emit_kernel'):
         if key in name:
             return key
