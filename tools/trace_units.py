@@ -16,7 +16,7 @@ from igtmpc.scenarios import make_batch
 DT = os.environ.get('IGT_PROBE_DTYPE', 'f64')
 b = make_batch(B, dtype=np.float32 if DT == 'f32' else np.float64)
 args = [torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda() for a in (b['x0'], b['u_prev'], b['kparams'], b['flags'], b['obs_xy'])]
-with BatchSolver(dtype=DT) as s:
+with BatchSolver(dtype=DT, cand_mode=os.environ.get('IGT_PROBE_CAND', 'lattice')) as s:
     s.set_cinf(*cinf_halfplanes())           # the benchmark's configuration (bench.py): terminal set on
     for _ in range(3):
         s.solve(*args)
