@@ -111,7 +111,8 @@ class MPC_Planner:
     def __init__(self, N=10, dt=0.1, agents=None, goals=None, ca_radius=2.8, ref=None, road_dim=(10, 50),
                  routes=None, ds_right=None, index=None, num_rk4_steps=7, solver='ipopt', ca_type='circle',
                  nn_config_dir=None, use_NN_cost2go=False, weights=(1, 1, 1),
-                 C=256, device=0, dtype='f64', value_net=None, cand_mode='track', refine_iters=0, track_env=None):
+                 C=256, device=0, dtype='f64', value_net=None, cand_mode='track', refine_iters=0, track_env=None,
+                 warm_start=None):
         assert agents is not None, 'Agents are not defined'           # mpc.py:155
         assert index is not None                                      # mpc.py:80
         if ca_type != 'circle':
@@ -149,6 +150,9 @@ class MPC_Planner:
         self.C_inf = cinf_halfplanes(dt=dt, jerk=self.jerk_limit)
         cost_mode = 'value_net' if use_NN_cost2go else 'progress'
         self.cand_mode = cand_mode
+        # whether solve() centres the candidates on u_sol_prev: default on for ramp-hold, off for the tracking family
+        # (igtmpc.evaluate.run_closed_loop has the closed-loop figures behind that default)
+        self.warm_start = (cand_mode == 'ramp_hold') if warm_start is None else (bool(warm_start) and cand_mode in ('ramp_hold', 'track'))
         include_route = False
         if use_NN_cost2go and value_net is None:
             if nn_config_dir is None:
@@ -223,12 +227,13 @@ class MPC_Planner:
     def solve(self, x_sol_prev=None, u_sol_prev=None):
         """-> (x[7,N+1], u[2,N], True) or (None, None, False); never raises on an infeasible problem.
         u_sol_prev[2,N] -- what evaluate.py:478-482 passes after augment_prev_sol -- is the warm start: IPOPT started
-        its iterations there (mpc.py:386-389), the shooting solver centres its ramp-hold candidates there, so the
-        shifted previous plan is itself one of the candidates.  x_sol_prev has no counterpart (states are implied)."""
+        its iterations there (mpc.py:386-389), the shooting solver centres its candidates there when `warm_start` is on
+        (default: ramp-hold yes, tracking no), so that the shifted previous plan is itself one of the candidates.
+        x_sol_prev has no counterpart (states are implied)."""
         flags = np.array([1 if self._abs_heading[self.ind] else 0], dtype=np.uint32)
         kp = np.array([self.K.kparams], dtype=self._dt)
         u_ws = None
-        if u_sol_prev is not None and self.cand_mode in ('ramp_hold', 'track'):
+        if u_sol_prev is not None and self.warm_start:
             u_ws = np.ascontiguousarray(np.asarray(u_sol_prev, dtype=self._dt).reshape(1, 2, self.N))
             flags = flags | np.uint32(IGT_FLAG_WARM)
         t0 = time.time()

@@ -271,8 +271,8 @@ def test_closed_loop_replayed_from_a_stream_graph_equals_the_eager_loop(golden_d
     while f'sc1_W{i}' in v:
         layers.append((v[f'sc1_W{i}'], v[f'sc1_b{i}']))
         i += 1
-    for kw in (dict(sc=2, cand_mode='track'), dict(sc=7, cand_mode='lattice'),
-               dict(sc=1, cand_mode='track', eval_mode='gt_mpc', value_net=dict(layers=layers))):
+    for kw in (dict(sc=2, cand_mode='track', warm_start=True), dict(sc=2, cand_mode='track'), dict(sc=7, cand_mode='lattice'),
+               dict(sc=1, cand_mode='track', warm_start=True, eval_mode='gt_mpc', value_net=dict(layers=layers))):
         a = run_closed_loop(num_samples=8, N=20, T_sim=3.0, device_resident=True, **kw)
         b = run_closed_loop(num_samples=8, N=20, T_sim=3.0, device_resident=True, graph=True, **kw)
         assert np.array_equal(a['x_data'], b['x_data']) and np.array_equal(a['u_data'], b['u_data']), kw
@@ -558,7 +558,8 @@ def test_closed_loop_matches_oracle_loop(cand_mode):
     for sel, terminal in (([0, 1, 3], True), ([2], False)):
         vcap = 1.0 if terminal else 0.0
         got = run_closed_loop(N=20, T_sim=3.0, dtype='f64', cand_mode=cand_mode, init=(x[sel], [pairs[e] for e in sel]),
-                              terminal_set=terminal, limits=dict(track_vcap=vcap) if cand_mode == 'track' else None)
+                              terminal_set=terminal, limits=dict(track_vcap=vcap) if cand_mode == 'track' else None,
+                              warm_start=True)      # (the tracking family's default is off: asked for, as the oracle loop has it)
         cinf = cinf_halfplanes() if terminal else (None, None)
         for q, e in enumerate(sel):
             ref = CL.run_episode(x[e], pairs[e], P, cinf, M_sim=30, cand_mode=cand_mode,
@@ -598,9 +599,9 @@ def test_closed_loop_gt_mpc_matches_oracle_loop(cand_mode, N):
     M_sim = 24 if N == 20 else 12
     P = O.Params(N=N)
     got = run_closed_loop(N=N, T_sim=M_sim * 0.1, dtype='f64', cand_mode=cand_mode, init=(x, pairs), eval_mode='gt_mpc',
-                          value_net=net)
+                          value_net=net, warm_start=True)
     dev = run_closed_loop(N=N, T_sim=M_sim * 0.1, dtype='f64', cand_mode=cand_mode, init=(x, pairs), eval_mode='gt_mpc',
-                          value_net=net, device_resident=True)
+                          value_net=net, device_resident=True, warm_start=True)
     assert np.array_equal(got['x_data'], dev['x_data']) and np.array_equal(got['u_data'], dev['u_data'])
     ev = dict(fallback=0, stop=0, share=0, share_retry=0, warm=0)
     for e in range(len(pairs)):
@@ -780,7 +781,7 @@ def test_driver_command_line_writes_the_reference_run_directory(tmp_path, mode):
         ucl = pickle.load(f)
     assert cl.shape == (3, 14, 151) and ucl.shape == (3, 4, 150) and np.isfinite(cl).all() and np.isfinite(ucl).all()
     assert (cl[:, 2::7, -1] >= cl[:, 2::7, 0]).all() and (cl[:, 5::7, 0] == 0).all()    # a standing start (v0 = 0), nobody rolled back
-    assert mode == 'gt_mpc' or (cl[:, 2::7, -1] > cl[:, 2::7, 0] + 20).all()          # (the shipped value nets run without their statistics)
+    assert mode == 'gt_mpc' or (cl[:, 2::7, -1] > cl[:, 2::7, 0] + 15).all()          # everybody made way (the shipped value nets run without their statistics)
     with open(sub + ('/stats.csv' if mode == 'gt_mpc' else '/eval_stats.csv'), newline='') as f:
         rows = list(csv.DictReader(f))
     assert len(rows) == 3 and ('NN_query_time' in rows[0]) == (mode == 'gt_mpc')
@@ -804,7 +805,7 @@ def test_closed_loop_with_the_policy_files_other_settings_matches_oracle_loop():
         x[2, m] = (xy[0], xy[1], s0, 0.0, 0.0, v0, float(R.psi_ref(R.ROUTE_ID[r], s0)))
     x[2, 0, 3] = 0.25
     P = O.Params(N=20)
-    kw = dict(N=20, T_sim=2.5, dtype='f64', cand_mode='track', init=(x, pairs), a_min_policy=-2.5, constant_speed=True)
+    kw = dict(N=20, T_sim=2.5, dtype='f64', cand_mode='track', init=(x, pairs), a_min_policy=-2.5, constant_speed=True, warm_start=True)
     got = run_closed_loop(**kw)
     dev = run_closed_loop(device_resident=True, **kw)
     plain = run_closed_loop(**dict(kw, constant_speed=False))
