@@ -56,8 +56,9 @@ def auto_track_env(N, dt):
     1 is the derived value -- the stationary acceleration of the NLP's own cost -- and the best setting from a 4 s horizon
     on (mpc.yaml:6 ships N = 40, dt = 0.1); a plan that is optimal over a shorter horizon runs faster into conflicts it
     cannot see yet, so the scale shrinks with the horizon, not below 0.25.  Measured (tools/envelope_sweep.py, 512 episodes):
-    N = 20: 0.5 -> 10 % infeasible steps / 29 % deadlock flag / 46.8 m against 15.6 % / 41 % / 43.1 m at 1.0;
-    N = 40: 1.0 -> 6.1 % / 4.1 % / 54.3 m.  The library's own default stays 1.0 (one solve knows no closed loop)."""
+    N = 20: 0.5 -> 9.2 % infeasible steps / 23 % deadlock flag / 47.6 m against 14.9 % / 29 % / 46.4 m at 1.0;
+    N = 40: 1.0 -> 3.3 % / 2.9 % / 60.1 m (0.5: 3.0 % / 2.5 % / 61.1 m) -- round 4, speed cap on, no warm start.
+    The library's own default stays 1.0 (one solve knows no closed loop)."""
     return float(min(1.0, max(0.25, N * dt / 4.0)))
 
 
