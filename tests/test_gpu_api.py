@@ -499,6 +499,22 @@ def test_mpc_planner_warm_start_sequence_matches_oracle():
                                track=dict(env=dflt.track_env))[-1]
     assert dflt.track_env == 0.5          # horizon-aware default (igtmpc.evaluate.auto_track_env): N dt = 2 s of 4
     assert okd == (rd['status'][0] == 0) and (not okd or rel_err(xd, rd['x'][0]).max() < 1e-9)
+    # the tracking family's default takes solve(x_sol_prev, u_sol_prev) as the reference passes it and does NOT centre its
+    # candidates there (warm_start=None: ramp-hold yes, tracking no -- DESIGN section 9); warm_start=True does, as the oracle does
+    assert okd and not dflt.warm_start
+    hint = np.stack([np.full(N, -1.5), np.zeros(N)])          # (far enough below the envelope that no offset reaches it)
+    xh, uh, okh = dflt.solve(x_sol_prev=xd, u_sol_prev=hint)
+    assert okh and np.array_equal(xh, xd) and np.array_equal(uh, ud)
+    wt = igtmpc.MPC_Planner(N=N, dt=0.1, ca_radius=2.8, agents=agents, routes=routes, ref=refs, goals=None,
+                            road_dim=(11.4, 50), ds_right=8.6, index=i, num_rk4_steps=4, warm_start=True)
+    wt.update_initial_condition(agents[i], inputs[i])
+    wt.update_predictions(preds, raw_preds=preds)
+    xw_, uw_, okw = wt.solve(x_sol_prev=xd, u_sol_prev=hint)
+    rw = O.solve_batch_refined(np.array([st0.state7()]), np.array([[0.1, 0.0]]), np.array([wt.K.kparams]), np.array([O.FLAG_WARM], np.uint32),
+                               np.array([[[[p.x for p in preds[1]], [p.y for p in preds[1]]]]]), *wt.C_inf, P, cand='track',
+                               track=dict(env=wt.track_env), u_ws=hint[None])[-1]
+    assert wt.warm_start and okw == (rw['status'][0] == 0) and (not okw or rel_err(xw_, rw['x'][0]).max() < 1e-9)
+    assert not okw or not np.array_equal(uw_, ud)          # the hint moved the candidates
     pl = igtmpc.MPC_Planner(N=N, dt=0.1, ca_radius=2.8, agents=agents, routes=routes, ref=refs, goals=None,
                             road_dim=(11.4, 50), ds_right=8.6, index=i, num_rk4_steps=4, cand_mode='ramp_hold')
     assert pl.cand_mode == 'ramp_hold' and pl._solver.dtype == 'f64'
